@@ -1,0 +1,174 @@
+/*
+ * qpalm_gfx950.h -- C ABI of the MI355X (gfx950) backend for the QPALM semismooth-Newton path.
+ *
+ * This is the drop-in boundary: plain C, `extern "C"`, caller-owned host buffers, int status codes,
+ * no torch / C++ types.  It replaces what the reference reaches through its compile-time solver
+ * backend (include/types.h:17-32 typedef block + include/solver_interface.h) and the API of
+ * include/qpalm.h for a BATCH of independent QPs whose state lives in HBM.
+ *
+ * Reference interface replaced by each entry point (paths relative to Benny44/QPALM):
+ *
+ *   qpg_batch_create / qpg_batch_set_problem / qpg_batch_setup
+ *        qpalm_setup                      include/qpalm.h:59-60,   src/qpalm.c:73-319
+ *        (validate_data/validate_settings src/validate.c:18-221,  scale_data src/scaling.c:34-113)
+ *   qpg_batch_warm_start                  qpalm_warm_start  include/qpalm.h:71-73, src/qpalm.c:322-399
+ *   qpg_batch_solve / qpg_batch_iterate   qpalm_solve       include/qpalm.h:82,    src/qpalm.c:401-736
+ *   qpg_batch_update_settings/bounds/q    qpalm_update_*    include/qpalm.h:95-126, src/qpalm.c:739-871
+ *   qpg_batch_destroy                     qpalm_cleanup     include/qpalm.h:133,   src/qpalm.c:874-1096
+ *   qpg_mat_vec / qpg_mat_tpose_vec       mat_vec / mat_tpose_vec          include/solver_interface.h:33,47
+ *   qpg_ldlchol                           ldlchol                           include/solver_interface.h:172
+ *   qpg_ldlcholQAtsigmaA                  ldlcholQAtsigmaA                  include/solver_interface.h:185
+ *   qpg_ldlupdate_entering_constraints    ldlupdate_entering_constraints    include/solver_interface.h:196
+ *   qpg_ldldowndate_leaving_constraints   ldldowndate_leaving_constraints   include/solver_interface.h:207
+ *   qpg_ldlupdate_sigma_changed           ldlupdate_sigma_changed           include/solver_interface.h:218
+ *   qpg_ldlsolveLD_neg_dphi               ldlsolveLD_neg_dphi               include/solver_interface.h:228
+ *   qpg_exact_linesearch                  exact_linesearch                  include/linesearch.h, src/linesearch.c:14-120
+ *   qpg_compute_residuals                 compute_residuals                 include/iteration.h,  src/iteration.c:24-48
+ *   qpg_set_active_constraints            set_active_constraints + set_entering_leaving_constraints src/newton.c:122-149
+ *
+ * All functions return QPG_OK (0) or a negative error code; qpg_last_error() gives the message.
+ * There is NO CPU fallback: without a usable gfx950 device every entry point fails.
+ */
+#ifndef QPALM_GFX950_H
+#define QPALM_GFX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t qpg_int;   /* == c_int  (CMakeLists.txt:53 -DDLONG, include/global_opts.h:31-39) */
+typedef double  qpg_float; /* == c_float (include/global_opts.h:61) */
+
+#define QPG_OK 0
+#define QPG_ERR_NO_DEVICE (-1)
+#define QPG_ERR_INVALID (-2)
+#define QPG_ERR_ALLOC (-3)
+#define QPG_ERR_RUNTIME (-4)
+#define QPG_ERR_UNSUPPORTED (-5)
+
+/* == QPALMSettings, include/types.h:119-150 (same field order; ABI witnessed by
+ *    interfaces/python/qpalm.py:49-80) */
+typedef struct {
+  qpg_int   max_iter;
+  qpg_int   inner_max_iter;
+  qpg_float eps_abs;
+  qpg_float eps_rel;
+  qpg_float eps_abs_in;
+  qpg_float eps_rel_in;
+  qpg_float rho;
+  qpg_float eps_prim_inf;
+  qpg_float eps_dual_inf;
+  qpg_float theta;
+  qpg_float delta;
+  qpg_float sigma_max;
+  qpg_float sigma_init;
+  qpg_int   proximal;
+  qpg_float gamma_init;
+  qpg_float gamma_upd;
+  qpg_float gamma_max;
+  qpg_int   scaling;
+  qpg_int   nonconvex;
+  qpg_int   verbose;
+  qpg_int   print_iter;
+  qpg_int   warm_start;
+  qpg_int   reset_newton_iter;
+  qpg_int   enable_dual_termination;
+  qpg_float dual_objective_limit;
+  qpg_float time_limit;
+  qpg_int   ordering;
+  qpg_int   factorization_method;
+  qpg_int   max_rank_update;
+  qpg_float max_rank_update_fraction;
+} QPGSettings;
+
+/* == QPALMInfo with PROFILING, include/types.h:76-95 */
+typedef struct {
+  qpg_int   iter;
+  qpg_int   iter_out;
+  char      status[32];
+  qpg_int   status_val;
+  qpg_float pri_res_norm;
+  qpg_float dua_res_norm;
+  qpg_float dua2_res_norm;
+  qpg_float objective;
+  qpg_float dual_objective;
+  qpg_float setup_time;
+  qpg_float solve_time;
+  qpg_float run_time;
+} QPGInfo;
+
+/* device-side work counters of one QP (for the roofline accounting) */
+typedef struct {
+  qpg_int n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma;
+  qpg_int nb_active, nb_enter, nb_leave, last_kind, last_fact;
+  qpg_float gamma, tau, eta, beta, eps_pri, eps_dua, eps_dua_in, sc_c;
+  qpg_float ms_total, ms_factor, ms_update, ms_solve, ms_linesearch;
+} QPGStats;
+
+typedef struct qpg_ctx qpg_ctx;
+typedef struct qpg_batch qpg_batch;
+
+const char *qpg_last_error(void);
+const char *qpg_backend_name(void); /* "gfx950-hip" for the shipped library */
+
+void qpg_set_default_settings(QPGSettings *s);          /* src/qpalm.c:38-70 */
+int  qpg_validate_settings(const QPGSettings *s);       /* 1 = valid, src/validate.c:43-221 */
+
+int  qpg_ctx_create(int device, qpg_ctx **out);
+void qpg_ctx_destroy(qpg_ctx *ctx);
+int  qpg_ctx_set_option(qpg_ctx *ctx, const char *name, qpg_int value); /* "lds_bytes", "max_slots",
+                                                                           "update_rank_threshold" */
+
+/* A batch = B QPs with the same (n, m).  nnzA_max / nnzQ_max bound the entries of any member. */
+int  qpg_batch_create(qpg_ctx *ctx, qpg_int B, qpg_int n, qpg_int m, qpg_int nnzA_max, qpg_int nnzQ_max,
+                      const QPGSettings *settings, qpg_batch **out);
+/* CSC, 64-bit indices as in cholmod_sparse; Q symmetric, only entries with row >= col are read
+ * (stype = -1, B6).  Data is copied. */
+int  qpg_batch_set_problem(qpg_batch *bt, qpg_int idx, const qpg_int *Qp, const qpg_int *Qi, const qpg_float *Qx,
+                           const qpg_int *Ap, const qpg_int *Ai, const qpg_float *Ax, const qpg_float *q,
+                           qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
+int  qpg_batch_setup(qpg_batch *bt);                               /* upload + Ruiz scaling on device */
+int  qpg_batch_warm_start(qpg_batch *bt, const qpg_float *x, const qpg_float *y); /* [B][n], [B][m] or NULL */
+int  qpg_batch_solve(qpg_batch *bt);                               /* run every QP to termination */
+int  qpg_batch_iterate(qpg_batch *bt, qpg_int k);                  /* at most k more loop iterations each */
+int  qpg_batch_num_unfinished(qpg_batch *bt, qpg_int *count);
+int  qpg_batch_update_settings(qpg_batch *bt, const QPGSettings *s);
+int  qpg_batch_update_bounds(qpg_batch *bt, const qpg_float *bmin, const qpg_float *bmax); /* [B][m] or NULL */
+int  qpg_batch_update_q(qpg_batch *bt, const qpg_float *q);                              /* [B][n] */
+int  qpg_batch_get_info(qpg_batch *bt, qpg_int idx, QPGInfo *out);
+int  qpg_batch_get_stats(qpg_batch *bt, qpg_int idx, QPGStats *out);
+int  qpg_batch_get_solution(qpg_batch *bt, qpg_float *x, qpg_float *y);                  /* [B][n], [B][m] */
+int  qpg_batch_get_vector(qpg_batch *bt, const char *name, qpg_int idx, qpg_float *out, qpg_int len);
+int  qpg_batch_set_vector(qpg_batch *bt, const char *name, qpg_int idx, const qpg_float *in, qpg_int len);
+int  qpg_batch_get_ivector(qpg_batch *bt, const char *name, qpg_int idx, qpg_int *out, qpg_int len);
+int  qpg_batch_set_ivector(qpg_batch *bt, const char *name, qpg_int idx, const qpg_int *in, qpg_int len);
+int  qpg_batch_set_scalar(qpg_batch *bt, const char *name, qpg_int idx, qpg_float v);   /* "gamma", ... */
+int  qpg_batch_get_factor(qpg_batch *bt, qpg_int idx, qpg_float *L_colmajor, qpg_float *D, qpg_int n);
+void qpg_batch_destroy(qpg_batch *bt);
+/* raw device pointers (for harnesses that keep data resident, e.g. torch tensors via from_dlpack) */
+int  qpg_batch_device_ptr(qpg_batch *bt, const char *name, void **ptr, size_t *bytes);
+int  qpg_batch_sync(qpg_batch *bt);
+
+/* ---- solver_interface.h surface, acting on QP `idx` of the batch (device-resident state) ---- */
+int qpg_mat_vec(qpg_batch *bt, qpg_int idx, int which /* 'A' or 'Q' */, const qpg_float *x, qpg_float *y);
+int qpg_mat_tpose_vec(qpg_batch *bt, qpg_int idx, int which, const qpg_float *x, qpg_float *y);
+int qpg_ldlchol(qpg_batch *bt, qpg_int idx);               /* factor Q (+ I/gamma if proximal) */
+int qpg_ldlcholQAtsigmaA(qpg_batch *bt, qpg_int idx);
+int qpg_ldlupdate_entering_constraints(qpg_batch *bt, qpg_int idx);
+int qpg_ldldowndate_leaving_constraints(qpg_batch *bt, qpg_int idx);
+int qpg_ldlupdate_sigma_changed(qpg_batch *bt, qpg_int idx);
+int qpg_ldlsolveLD_neg_dphi(qpg_batch *bt, qpg_int idx);
+int qpg_compute_residuals(qpg_batch *bt, qpg_int idx);
+int qpg_set_active_constraints(qpg_batch *bt, qpg_int idx);
+int qpg_exact_linesearch(qpg_batch *bt, qpg_int idx, qpg_float *tau);
+/* batched LDL^T solve of the current factors with right-hand side dphi (the kernel the metric's
+ * "HBM GB/s on LDL" refers to): every QP of the batch, `reps` times, for benchmarking. */
+int qpg_batch_ldlsolve_all(qpg_batch *bt, qpg_int reps, float *ms_per_rep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,54 @@
+"""Build helpers.  The product library is hipcc-only (gfx950); the emulation build is test-only."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libqpalm_gfx950.so")
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libqpalm_gfx950_emu.so")
+_SRCS = ["qpalm_gfx950.hip", "qpalm_kernels.h", "qpalm_device.h", "qpalm_dense.h", "qpalm_iter.h", "qpalm_types.h",
+         "qpalm_capi.inc"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in _SRCS] + [os.path.join(ROOT, "include", "qpalm_gfx950.h")]
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    if not force and not _stale(LIB, _deps()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wno-unused-value", "-o", LIB, os.path.join(CSRC, "qpalm_gfx950.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_emu(force=False, block=128):
+    """TEST-ONLY: the same kernel source compiled for the host against tests/emu/hip_emu.h."""
+    deps = _deps() + [os.path.join(EMU_DIR, f) for f in ("hip_emu.h", "hip_emu.cpp", "qpalm_emu.cpp")]
+    if not force and not _stale(EMU_LIB, deps):
+        return EMU_LIB
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DQP_T=%d" % block,
+           "-Wno-unknown-pragmas", os.path.join(EMU_DIR, "qpalm_emu.cpp"), os.path.join(EMU_DIR, "hip_emu.cpp"),
+           "-o", EMU_LIB]
+    subprocess.check_call(cmd)
+    return EMU_LIB
+
+
+def build_oracle(force=False):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"] + (["-B"] if force else []))
+    return os.path.join(ROOT, "oracle", "libqpalm_oracle.so")

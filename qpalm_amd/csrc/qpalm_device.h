@@ -1,0 +1,200 @@
+/*
+ * qpalm_device.h -- gfx950 device code of the QPALM inner loop (one workgroup == one QP).
+ *
+ * Execution model: a persistent workgroup of QP_T threads (QP_T/64 wavefronts, 64 lanes each) owns
+ * one QP at a time and runs the whole semismooth-Newton loop of qpalm_solve (src/qpalm.c:484-711)
+ * for it: residuals + termination reductions, active-set compaction, LDL^T factor / rank-k
+ * update / triangular solves on a dense column-major panel in HBM, CSC SpMVs, the exact line search
+ * (LDS bitonic sort + scan) and the primal update.  Independent QPs never communicate, so there is
+ * no inter-workgroup synchronisation at all; control flow is workgroup-uniform.
+ *
+ * Arithmetic policy: the element-wise "host arithmetic" of the reference (lin_alg.c loops) is
+ * reproduced operation by operation WITHOUT fused multiply-add (the file is compiled with
+ * -ffp-contract=off) so that those results are bit-identical to a CPU build of the reference;
+ * explicit fma() is used only inside SpMV dots and the dense LDL^T kernels.
+ *
+ * The same source is compiled for the host against tests/emu/hip_emu.h (QPALM_EMU) to debug the
+ * logic without a GPU; that build is test-only.
+ */
+#ifndef QPALM_DEVICE_H
+#define QPALM_DEVICE_H
+
+#include "qpalm_types.h"
+
+#ifndef QP_T
+#define QP_T 512
+#endif
+#define QP_NW (QP_T / 64)
+#define QPD __device__ __forceinline__
+#define QPN __device__ __forceinline__
+
+#ifdef QPALM_EMU
+typedef emu_double4 qp_double4;
+#define QP_MFMA_F64(a, b, c) emu_mfma_f64_16x16x4((a), (b), (c))
+#define QP_DYN_LDS() (emu::dyn_lds())
+#define QP_FMA(a, b, c) std::fma((a), (b), (c))
+#define QP_SQRT(x) std::sqrt(x)
+#define QP_CLOCK() ((long long)wall_clock64())
+#define QP_UNIFORM(x) (x)
+#define QP_OPAQUE(x) do { } while (0)
+#else
+typedef double qp_double4 __attribute__((ext_vector_type(4)));
+#define QP_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+extern __shared__ __attribute__((aligned(16))) char qp_dyn_lds_[];
+#define QP_DYN_LDS() (qp_dyn_lds_)
+#define QP_FMA(a, b, c) fma((a), (b), (c))
+#define QP_SQRT(x) sqrt(x)
+#define QP_CLOCK() ((long long)wall_clock64())
+#define QP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x) /* value is wave-uniform: keep it in an SGPR */
+/* stops LICM/CSE from keeping ~100 per-array addresses live across the whole iteration loop */
+#define QP_OPAQUE(x) asm volatile("" : "+s"(x))
+#endif
+
+/* ---- c_max / c_min / c_absval exactly as the reference's macros (include/global_opts.h) ---- */
+QPD double qmax(double a, double b) { return (a > b) ? a : b; }
+QPD double qmin(double a, double b) { return (a < b) ? a : b; }
+QPD double qabs(double x) { return (x < 0) ? -x : x; }
+
+/* =============================================================================================
+ * workgroup primitives
+ * =========================================================================================== */
+#define QP_NRED 20
+struct QpShared {          /* small static LDS block */
+  double red[QP_NW][QP_NRED];
+  double bc[QP_NRED];      /* broadcast scalars */
+  int    ired[QP_NW][4];
+  int    ibc[8];
+};
+
+QPD double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+QPD double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) { double u = __shfl_xor(v, o); v = (u > v) ? u : v; }
+  return v;
+}
+QPD int wave_isum(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+QPD int wave_imin(int v) {
+  for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = (u < v) ? u : v; }
+  return v;
+}
+
+/* Reduce NM maxima and NS sums over the workgroup; every thread receives the results.
+ * Fixed tree (butterfly inside a wavefront, wavefronts combined in index order) => deterministic. */
+template <int NM, int NS>
+QPD void block_reduce(QpShared &S, double *vm, double *vs) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NM; k++) vm[k] = wave_max(vm[k]);
+#pragma unroll
+  for (int k = 0; k < NS; k++) vs[k] = wave_sum(vs[k]);
+  __syncthreads(); /* S.red may still be read by a previous reduction's consumers */
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NM; k++) S.red[wid][k] = vm[k];
+#pragma unroll
+    for (int k = 0; k < NS; k++) S.red[wid][NM + k] = vs[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NM; k++) {
+    double v = S.red[0][k];
+    for (int w = 1; w < QP_NW; w++) { double u = S.red[w][k]; v = (u > v) ? u : v; }
+    vm[k] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    double v = S.red[0][NM + k];
+    for (int w = 1; w < QP_NW; w++) v += S.red[w][NM + k];
+    vs[k] = v;
+  }
+}
+
+QPD int block_isum(QpShared &S, int v) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = wave_isum(v);
+  __syncthreads();
+  if (lane == 0) S.ired[wid][0] = v;
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < QP_NW; w++) t += S.ired[w][0];
+  return t;
+}
+QPD int block_imin(QpShared &S, int v) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = wave_imin(v);
+  __syncthreads();
+  if (lane == 0) S.ired[wid][1] = v;
+  __syncthreads();
+  int t = S.ired[0][1];
+  for (int w = 1; w < QP_NW; w++) t = (S.ired[w][1] < t) ? S.ired[w][1] : t;
+  return t;
+}
+
+/* Ordered stream compaction: out[] receives, ascending, every i in [0,count) with flag(i) != 0.
+ * Two lists are produced in one pass (enter / leave of newton.c:134-149).  Returns the counts via
+ * S.ibc[0..1] (valid for all threads after the call). */
+template <class F0, class F1>
+QPD void block_compact2(QpShared &S, int count, F0 f0, F1 f1, int *out0, int *out1, int &n0, int &n1) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int base0 = 0, base1 = 0;
+  for (int i0 = 0; i0 < count; i0 += QP_T) {
+    const int i = i0 + (int)threadIdx.x;
+    const int p0 = (i < count) ? (f0(i) ? 1 : 0) : 0;
+    const int p1 = (i < count) ? (f1(i) ? 1 : 0) : 0;
+    const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int pre0 = __popcll(b0 & below), pre1 = __popcll(b1 & below);
+    __syncthreads();
+    if (lane == 0) { S.ired[wid][2] = __popcll(b0); S.ired[wid][3] = __popcll(b1); }
+    __syncthreads();
+    int w0 = 0, w1 = 0, t0 = 0, t1 = 0;
+    for (int w = 0; w < QP_NW; w++) {
+      if (w < wid) { w0 += S.ired[w][2]; w1 += S.ired[w][3]; }
+      t0 += S.ired[w][2]; t1 += S.ired[w][3];
+    }
+    if (p0) out0[base0 + w0 + pre0] = i;
+    if (p1) out1[base1 + w1 + pre1] = i;
+    base0 += t0; base1 += t1;
+  }
+  n0 = base0; n1 = base1;
+  __syncthreads();
+}
+
+/* y[r] = sum_k val[k] * x[idx[k]], k in [ptr[r], ptr[r+1]) -- one sub-wavefront of G lanes per
+ * compressed column/row, coalesced walk of idx/val, butterfly reduce.  Used for A'*yh (CSC of A),
+ * A*d (CSC of A') and Q*d (full symmetric pattern).  post(r, sum) consumes the result. */
+template <int G, class Post>
+QPD void spmv_rows(int nrows, const int *__restrict__ ptr, const int *__restrict__ idx,
+                   const double *__restrict__ val, const double *x, Post post) {
+  const int sub = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+  for (int r0 = 0; r0 < nrows; r0 += QP_T / G) {
+    const int r = r0 + grp;
+    double acc = 0.0;
+    if (r < nrows) {
+      const int k1 = ptr[r + 1];
+      for (int k = ptr[r] + sub; k < k1; k += G) acc = QP_FMA(val[k], x[idx[k]], acc);
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (r < nrows && sub == 0) post(r, acc);
+  }
+}
+
+/* per-QP pointer helpers */
+struct QpPtr {
+  const qpg_view &V; int b;
+  QPD QpPtr(const qpg_view &v, int bb) : V(v), b(bb) {}
+  QPD double *vn(double *base) const { return base + (size_t)b * V.n; }
+  QPD double *vm(double *base) const { return base + (size_t)b * V.m; }
+  QPD int *im(int *base) const { return base + (size_t)b * V.m; }
+};
+
+#include "qpalm_dense.h"
+#include "qpalm_iter.h"
+
+#endif

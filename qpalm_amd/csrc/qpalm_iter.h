@@ -1,0 +1,801 @@
+/*
+ * qpalm_iter.h -- the QPALM iteration as device code: one workgroup drives one QP through
+ * scale_data (src/scaling.c:34-113), qpalm_warm_start (src/qpalm.c:322-399) and the loop body of
+ * qpalm_solve (src/qpalm.c:484-711): compute_residuals (iteration.c:24-48), check_termination
+ * (termination.c:19-240), the outer update (qpalm.c:515-645: update_sigma, gamma logic), and the
+ * Newton step (newton.c:17-149, linesearch.c:14-120, iteration.c:213-229).
+ *
+ * Element-wise expressions are written in the reference's operation order (a + sc*b etc.) and this
+ * translation unit is compiled with -ffp-contract=off, so they round exactly like the C reference.
+ */
+#ifndef QPALM_ITER_H
+#define QPALM_ITER_H
+
+#define QP_KIND_NEWTON 0
+#define QP_KIND_OUTER 1
+#define QP_KIND_FORCED 2
+#define QP_KIND_TERMINATED 3
+
+struct IterShared {
+  QpShared S;
+  qpg_scalars s;
+  int kind, action, nL, pos;
+  double a0, b0;
+  double scan_a[QP_NW], scan_b[QP_NW];
+};
+
+struct QpArrays { /* per-QP views; base pointers are recomputed on use to keep SGPR pressure low */
+  const qpg_view *V; int b, n, m;
+  QPD const int *Ap() const { return V->Ap + (size_t)b * (V->n + 1); }
+  QPD const int *Ai() const { return V->Ai + (size_t)b * V->nnzA; }
+  QPD const int *Atp() const { return V->Atp + (size_t)b * (V->m + 1); }
+  QPD const int *Ati() const { return V->Ati + (size_t)b * V->nnzA; }
+  QPD const int *Atperm() const { return V->Atperm + (size_t)b * V->nnzA; }
+  QPD const int *Qp() const { return V->Qp + (size_t)b * (V->n + 1); }
+  QPD const int *Qi() const { return V->Qi + (size_t)b * V->nnzQ; }
+  QPD const int *Qfp() const { return V->Qfp + (size_t)b * (V->n + 1); }
+  QPD const int *Qfi() const { return V->Qfi + (size_t)b * V->nnzQf; }
+  QPD const int *Qfperm() const { return V->Qfperm + (size_t)b * V->nnzQf; }
+  QPD double *Ax() const { return V->Ax + (size_t)b * V->nnzA; }
+  QPD double *Atx() const { return V->Atx + (size_t)b * V->nnzA; }
+  QPD double *Atss() const { return V->Atss + (size_t)b * V->nnzA; }
+  QPD double *Qx() const { return V->Qx + (size_t)b * V->nnzQ; }
+  QPD double *Qfx() const { return V->Qfx + (size_t)b * V->nnzQf; }
+  QPD double *q() const { return V->q + (size_t)b * V->n; }
+  QPD double *x() const { return V->x + (size_t)b * V->n; }
+  QPD double *Qxv() const { return V->Qxv + (size_t)b * V->n; }
+  QPD double *Aty() const { return V->Aty + (size_t)b * V->n; }
+  QPD double *x_prev() const { return V->x_prev + (size_t)b * V->n; }
+  QPD double *x0() const { return V->x0 + (size_t)b * V->n; }
+  QPD double *Atyh() const { return V->Atyh + (size_t)b * V->n; }
+  QPD double *df() const { return V->df + (size_t)b * V->n; }
+  QPD double *dphi() const { return V->dphi + (size_t)b * V->n; }
+  QPD double *dphi_prev() const { return V->dphi_prev + (size_t)b * V->n; }
+  QPD double *d() const { return V->d + (size_t)b * V->n; }
+  QPD double *Qd() const { return V->Qd + (size_t)b * V->n; }
+  QPD double *delta_x() const { return V->delta_x + (size_t)b * V->n; }
+  QPD double *temp_n() const { return V->temp_n + (size_t)b * V->n; }
+  QPD double *D() const { return V->D + (size_t)b * V->n; }
+  QPD double *Dinv() const { return V->Dinv + (size_t)b * V->n; }
+  QPD double *sol_x() const { return V->sol_x + (size_t)b * V->n; }
+  QPD double *bmin() const { return V->bmin + (size_t)b * V->m; }
+  QPD double *bmax() const { return V->bmax + (size_t)b * V->m; }
+  QPD double *y() const { return V->y + (size_t)b * V->m; }
+  QPD double *Axv() const { return V->Axv + (size_t)b * V->m; }
+  QPD double *sigma() const { return V->sigma + (size_t)b * V->m; }
+  QPD double *sigma_inv() const { return V->sigma_inv + (size_t)b * V->m; }
+  QPD double *sqrt_sigma() const { return V->sqrt_sigma + (size_t)b * V->m; }
+  QPD double *At_scale() const { return V->At_scale + (size_t)b * V->m; }
+  QPD double *Axys() const { return V->Axys + (size_t)b * V->m; }
+  QPD double *z() const { return V->z + (size_t)b * V->m; }
+  QPD double *pri_res() const { return V->pri_res + (size_t)b * V->m; }
+  QPD double *pri_res_in() const { return V->pri_res_in + (size_t)b * V->m; }
+  QPD double *yh() const { return V->yh + (size_t)b * V->m; }
+  QPD double *Ad() const { return V->Ad + (size_t)b * V->m; }
+  QPD double *delta_y() const { return V->delta_y + (size_t)b * V->m; }
+  QPD double *temp_m() const { return V->temp_m + (size_t)b * V->m; }
+  QPD double *E() const { return V->E + (size_t)b * V->m; }
+  QPD double *Einv() const { return V->Einv + (size_t)b * V->m; }
+  QPD double *sol_y() const { return V->sol_y + (size_t)b * V->m; }
+  QPD double *ls_key() const { return V->ls_key + (size_t)b * V->ls_stride; }
+  QPD int *ls_idx() const { return V->ls_idx + (size_t)b * V->ls_stride; }
+  QPD double *ls_delta() const { return V->ls_delta + (size_t)b * (2 * V->m); }
+  QPD double *ls_alpha() const { return V->ls_alpha + (size_t)b * (2 * V->m); }
+  QPD int *active() const { return V->active + (size_t)b * V->m; }
+  QPD int *active_old() const { return V->active_old + (size_t)b * V->m; }
+  QPD int *enter() const { return V->enter + (size_t)b * V->m; }
+  QPD int *leave() const { return V->leave + (size_t)b * V->m; }
+};
+
+QPD QpArrays qp_arrays(const qpg_view &V, int b) {
+  QpArrays a;
+  a.V = &V; a.b = b; a.n = V.n; a.m = V.m;
+  return a;
+}
+
+/* =============================================================================================
+ * scale_data (src/scaling.c:34-113) and the derived copies (A' values, full-symmetric Q values)
+ * =========================================================================================== */
+QPN void dev_fill_derived(const qpg_view &V, const QpArrays &a, int b) {
+  const int nzA = a.Ap()[a.n], nzQf = a.Qfp()[a.n];
+  for (int k = threadIdx.x; k < nzA; k += QP_T) a.Atx()[k] = a.Ax()[a.Atperm()[k]];
+  for (int k = threadIdx.x; k < nzQf; k += QP_T) a.Qfx()[k] = a.Qx()[a.Qfperm()[k]];
+  __syncthreads();
+}
+
+QPN void dev_scale_data(const qpg_view &V, const QpArrays &a, int b, int nscale, IterShared &I) {
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  double *D_temp = a.temp_n(), *E_temp = a.temp_m();
+  for (int j = tid; j < n; j += QP_T) a.D()[j] = 1.0;
+  for (int i = tid; i < m; i += QP_T) a.E()[i] = 1.0;
+  __syncthreads();
+  for (int it = 0; it < nscale; it++) {
+    /* column / row infinity norms of A (solver_interface.c:276-314) */
+    for (int j = tid; j < n; j += QP_T) {
+      double e = 0.0;
+      for (int k = a.Ap()[j]; k < a.Ap()[j + 1]; k++) e = qmax(qabs(a.Ax()[k]), e);
+      e = e < 1e-12 ? 1.0 : e;            /* limit_scaling, scaling.c:25-31 */
+      D_temp[j] = 1.0 / QP_SQRT(e);
+    }
+    for (int i = tid; i < m; i += QP_T) {
+      double e = 0.0;
+      for (int k = a.Atp()[i]; k < a.Atp()[i + 1]; k++) e = qmax(qabs(a.Ax()[a.Atperm()[k]]), e);
+      e = e < 1e-12 ? 1.0 : e;
+      E_temp[i] = 1.0 / QP_SQRT(e);
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += QP_T) {   /* A <- diag(E_temp) A, then A <- A diag(D_temp) */
+      const double dj = D_temp[j];
+      for (int k = a.Ap()[j]; k < a.Ap()[j + 1]; k++) { double v = a.Ax()[k]; v *= E_temp[a.Ai()[k]]; v *= dj; a.Ax()[k] = v; }
+      a.D()[j] = a.D()[j] * dj;
+    }
+    for (int i = tid; i < m; i += QP_T) a.E()[i] = a.E()[i] * E_temp[i];
+    __syncthreads();
+  }
+  /* q <- D q ; Qx <- D Qx ; c = 1/max(1, ||Qx + q||inf) ; q <- c q   (scaling.c:83-89) */
+  double vm[1] = {0.0}, vs[1] = {0.0};
+  for (int j = tid; j < n; j += QP_T) {
+    const double qj = a.D()[j] * a.q()[j];
+    const double Qxj = a.D()[j] * a.Qxv()[j];
+    a.q()[j] = qj; a.Qxv()[j] = Qxj;
+    const double dp = Qxj + 1 * qj;
+    a.dphi()[j] = dp;
+    vm[0] = qmax(vm[0], qabs(dp));
+  }
+  block_reduce<1, 0>(I.S, vm, vs);
+  const double c = 1 / qmax(1.0, vm[0]);
+  for (int j = tid; j < n; j += QP_T) {
+    a.q()[j] *= c;
+    const double t = a.D()[j];
+    for (int k = a.Qp()[j]; k < a.Qp()[j + 1]; k++) { double v = a.Qx()[k]; v *= t * a.D()[a.Qi()[k]]; v *= c; a.Qx()[k] = v; }
+    a.Dinv()[j] = 1.0 / a.D()[j];
+  }
+  for (int i = tid; i < m; i += QP_T) {
+    a.Einv()[i] = 1.0 / a.E()[i];
+    a.bmin()[i] = a.E()[i] * a.bmin()[i];
+    a.bmax()[i] = a.E()[i] * a.bmax()[i];
+  }
+  if (tid == 0) { I.s.sc_c = c; I.s.sc_cinv = 1.0 / c; }
+  __syncthreads();
+}
+
+/* compute_objective, iteration.c:231-270 (the CPU groups terms by four; here a fixed tree) */
+QPN double dev_objective(const qpg_view &V, const QpArrays &a, IterShared &I, double c0) {
+  const qpg_settings &st = *V.settings;
+  double vm[1] = {0.0}, vs[1] = {0.0};
+  const double g = I.s.gamma;
+  for (int j = threadIdx.x; j < a.n; j += QP_T) {
+    if (st.proximal) vs[0] += (0.5 * (a.Qxv()[j] - 1 / g * a.x()[j]) + a.q()[j]) * a.x()[j];
+    else vs[0] += (0.5 * a.Qxv()[j] + a.q()[j]) * a.x()[j];
+  }
+  block_reduce<0, 1>(I.S, vm, vs);
+  double obj = vs[0];
+  if (I.s.has_scaling) obj *= I.s.sc_cinv;
+  obj += c0;
+  return obj;
+}
+
+/* qpalm_warm_start (qpalm.c:322-399) + initialize_sigma (iteration.c:50-84).
+ * The (unscaled) warm-start vectors were placed in x / y by the host; has_x / has_y say which. */
+QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, int has_y, IterShared &I) {
+  const qpg_settings &st = *V.settings;
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  if (tid == 0) I.s.gamma = st.gamma_init;
+  __syncthreads();
+  if (has_x) {
+    for (int j = tid; j < n; j += QP_T) {
+      double xv = a.x()[j];
+      if (I.s.has_scaling) xv = xv * a.Dinv()[j];
+      a.x()[j] = xv; a.x0()[j] = xv; a.x_prev()[j] = xv;
+    }
+    __syncthreads();
+    const double ginv = 1 / st.gamma_init;
+    const int prox = (int)st.proximal;
+    spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), a.x(), [&](int r, double s) {
+      a.Qd()[r] = s;
+      a.Qxv()[r] = prox ? (s + ginv * a.x()[r]) : s;
+    });
+    spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), a.x(), [&](int r, double s) { a.Ad()[r] = s; a.Axv()[r] = s; });
+    __syncthreads();
+    const double obj = dev_objective(V, a, I, V.c0[b]);
+    if (tid == 0) I.s.objective = obj;
+  } else {
+    for (int j = tid; j < n; j += QP_T) { a.x()[j] = 0.; a.x_prev()[j] = 0.; a.x0()[j] = 0.; a.Qxv()[j] = 0.; }
+    for (int i = tid; i < m; i += QP_T) a.Axv()[i] = 0.;
+    if (tid == 0) I.s.objective = 0.0;
+  }
+  if (has_y) {
+    for (int i = tid; i < m; i += QP_T) {
+      double yv = a.y()[i];
+      if (I.s.has_scaling) { yv = yv * a.Einv()[i]; yv *= I.s.sc_c; }
+      a.y()[i] = yv;
+    }
+  } else {
+    for (int i = tid; i < m; i += QP_T) a.y()[i] = 0.;
+  }
+  __syncthreads();
+  /* initialize_sigma */
+  double vm[1] = {0.0}, vs[3] = {0.0, 0.0, 0.0};
+  for (int j = tid; j < n; j += QP_T) { vs[0] += a.x()[j] * a.Qxv()[j]; vs[1] += a.q()[j] * a.x()[j]; }
+  for (int i = tid; i < m; i += QP_T) {
+    const double ax = a.Axv()[i];
+    const double mid = qmax(a.bmin()[i], qmin(ax, a.bmax()[i]));
+    const double t = ax + (-1) * mid;
+    vs[2] += t * t;
+  }
+  block_reduce<0, 3>(I.S, vm, vs);
+  const double f = 0.5 * vs[0] + vs[1], dist2 = vs[2];
+  const double sig = qmax(1e-4, qmin(st.sigma_init * qmax(1, qabs(f)) / qmax(1, 0.5 * dist2), 1e4));
+  const double ssig = QP_SQRT(sig), sinv = 1.0 / sig;
+  for (int i = tid; i < m; i += QP_T) {
+    a.sigma()[i] = sig; a.sigma_inv()[i] = sinv; a.sqrt_sigma()[i] = ssig; a.At_scale()[i] = ssig;
+    for (int k = a.Atp()[i]; k < a.Atp()[i + 1]; k++) a.Atss()[k] = a.Atx()[k] * ssig;
+  }
+  if (tid == 0) { I.s.sqrt_sigma_max = QP_SQRT(st.sigma_max); I.s.initialized = 1; }
+  __syncthreads();
+}
+
+/* =============================================================================================
+ * factorisation plumbing
+ * =========================================================================================== */
+template <int RPT>
+QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds); }
+template <int RPT>
+QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *up, int n_up,
+                    const int *dn, int n_dn, QpShared &S, char *lds) {
+  dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V, b, L, Dg, Wst, up, n_up, dn, n_dn, S, lds);
+}
+
+/* =============================================================================================
+ * update_sigma (iteration.c:86-145) + ldlupdate_sigma_changed (solver_interface.c:443-503)
+ * =========================================================================================== */
+template <int RPT>
+QPN void dev_update_sigma(const qpg_view &V, const QpArrays &a, int b, IterShared &I, double *L, double *Dg,
+                          double *Wst, char *lds) {
+  const qpg_settings &st = *V.settings;
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  double vm[1] = {0.0}, vs[1] = {0.0};
+  for (int i = tid; i < m; i += QP_T) vm[0] = qmax(vm[0], qabs(a.pri_res()[i]));
+  block_reduce<1, 0>(I.S, vm, vs);
+  const double prn = vm[0];
+  int *changed_flag = a.ls_idx(); /* scratch */
+  for (int k = tid; k < m; k += QP_T) {
+    int chg = 0;
+    if ((qabs(a.pri_res()[k]) > st.theta * qabs(a.pri_res_in()[k])) && a.active()[k]) {
+      double mult_factor = qmax(1.0, st.delta * qabs(a.pri_res()[k]) / (prn + 1e-6));
+      const double sigma_temp = mult_factor * a.sigma()[k];
+      if (sigma_temp <= st.sigma_max) {
+        if (a.sigma()[k] != sigma_temp) chg = 1;
+        a.sigma()[k] = sigma_temp;
+        a.sigma_inv()[k] = 1.0 / sigma_temp;
+        mult_factor = QP_SQRT(mult_factor);
+        a.sqrt_sigma()[k] = mult_factor * a.sqrt_sigma()[k];
+        a.At_scale()[k] = mult_factor;
+      } else {
+        if (a.sigma()[k] != st.sigma_max) chg = 1;
+        a.sigma()[k] = st.sigma_max;
+        a.sigma_inv()[k] = 1.0 / st.sigma_max;
+        a.At_scale()[k] = I.s.sqrt_sigma_max / a.sqrt_sigma()[k];
+        a.sqrt_sigma()[k] = I.s.sqrt_sigma_max;
+      }
+    } else a.At_scale()[k] = 1.0;
+    changed_flag[k] = chg;
+    const double sc = a.At_scale()[k];
+    if (sc != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= sc;
+  }
+  __syncthreads();
+  int nchg = 0, dummy = 0;
+  block_compact2(I.S, m, [&](int i) { return changed_flag[i]; }, [&](int i) { return 0; }, a.enter(), a.leave(), nchg, dummy);
+  if (tid == 0) { I.s.nb_sigma_changed = nchg; I.s.n_sigma_updates++; }
+  __syncthreads();
+  const double thr = qmin(st.max_rank_update_fraction * (double)(n + m), 0.25 * (double)st.max_rank_update);
+  if ((st.proximal && I.s.gamma < st.gamma_max) || ((double)nchg > thr)) {
+    if (tid == 0) I.s.reset_newton = 1;
+  } else if (nchg == 0) {
+  } else {
+    /* ldlupdate_sigma_changed */
+    for (int k = tid; k < nchg; k += QP_T) {
+      const int row = a.enter()[k];
+      double s = a.At_scale()[row];
+      s = s * s;
+      s = QP_SQRT(1 - 1 / s);
+      a.At_scale()[row] = s;
+      for (int e = a.Atp()[row]; e < a.Atp()[row + 1]; e++) a.Atss()[e] *= s;
+    }
+    __syncthreads();
+    dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds);
+    for (int k = tid; k < m; k += QP_T) {
+      const double s = 1.0 / a.At_scale()[k];
+      a.At_scale()[k] = s;
+      if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s;
+    }
+    if (tid == 0) { I.s.n_rank1 += nchg; }
+  }
+  __syncthreads();
+}
+
+/* update_gamma (iteration.c:147-156) */
+QPN void dev_update_gamma(const qpg_view &V, const QpArrays &a, IterShared &I) {
+  const qpg_settings &st = *V.settings;
+  __syncthreads();
+  if (I.s.gamma < st.gamma_max) {
+    const double prev = I.s.gamma;
+    const double g = qmin(prev * st.gamma_upd, st.gamma_max);
+    const double sc = 1 / g - 1 / prev;
+    for (int j = threadIdx.x; j < a.n; j += QP_T) a.Qxv()[j] = a.Qxv()[j] + sc * a.x()[j];
+    __syncthreads();
+    if (threadIdx.x == 0) { I.s.gamma = g; I.s.reset_newton = 1; }
+  }
+  __syncthreads();
+}
+
+/* set_active_constraints + set_entering_leaving_constraints (newton.c:122-149) */
+QPN void dev_active_sets(const QpArrays &a, IterShared &I) {
+  const int m = a.m;
+  int cnt = 0;
+  for (int i = threadIdx.x; i < m; i += QP_T) {
+    const int act = ((a.Axys()[i] <= a.bmin()[i]) || (a.Axys()[i] >= a.bmax()[i])) ? 1 : 0;
+    a.active()[i] = act;
+    cnt += act;
+  }
+  cnt = block_isum(I.S, cnt);
+  int ne = 0, nl = 0;
+  block_compact2(I.S, m, [&](int i) { return a.active()[i] && !a.active_old()[i]; },
+                 [&](int i) { return !a.active()[i] && a.active_old()[i]; }, a.enter(), a.leave(), ne, nl);
+  if (threadIdx.x == 0) { I.s.nb_active = cnt; I.s.nb_enter = ne; I.s.nb_leave = nl; }
+  __syncthreads();
+}
+
+/* boost_gamma (iteration.c:158-211) */
+QPN void dev_boost_gamma(const qpg_view &V, const QpArrays &a, int b, IterShared &I, double *L, char *lds) {
+  const qpg_settings &st = *V.settings;
+  const double prev = I.s.gamma;
+  double g;
+  if (I.s.nb_active) {
+    const double ub = form_schur<true>(V, b, L, true, false, 0.0, I.S, lds);
+    g = qmax(st.gamma_max, 1e14 / ub);
+    if (threadIdx.x == 0) I.s.gamma_maxed = 1;
+  } else g = 1e12;
+  __syncthreads();
+  if (prev != g) {
+    const double s1 = 1.0 / g - 1.0 / prev, s2 = I.s.tau / g - I.s.tau / prev;
+    for (int j = threadIdx.x; j < a.n; j += QP_T) {
+      a.Qxv()[j] = a.Qxv()[j] + s1 * a.x()[j];
+      a.Qd()[j] = a.Qd()[j] + s2 * a.d()[j];
+    }
+    if (threadIdx.x == 0) I.s.reset_newton = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { I.s.gamma = g; I.s.n_boost_gamma++; }
+  __syncthreads();
+}
+
+/* store_solution (termination.c:242-252); B12: yh is rescaled in place */
+QPN void dev_store_solution(const qpg_view &V, const QpArrays &a, int b, IterShared &I) {
+  __syncthreads();
+  if (I.s.has_scaling) {
+    for (int j = threadIdx.x; j < a.n; j += QP_T) a.sol_x()[j] = a.x()[j] * a.D()[j];
+    for (int i = threadIdx.x; i < a.m; i += QP_T) { const double v = a.yh()[i] * I.s.sc_cinv; a.yh()[i] = v; a.sol_y()[i] = v * a.E()[i]; }
+  } else {
+    for (int j = threadIdx.x; j < a.n; j += QP_T) a.sol_x()[j] = a.x()[j];
+    for (int i = threadIdx.x; i < a.m; i += QP_T) a.sol_y()[i] = a.yh()[i];
+  }
+  const double obj = dev_objective(V, a, I, V.c0[b]);
+  if (threadIdx.x == 0) I.s.objective = obj;
+  __syncthreads();
+}
+
+/* =============================================================================================
+ * exact_linesearch (linesearch.c:14-120): breakpoints -> LDS bitonic sort -> prefix scan
+ * =========================================================================================== */
+QPD bool ls_greater(double ka, int ia, double kb, int ib) { return (ka > kb) || (ka == kb && ia > ib); }
+
+QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, char *lds) {
+  const qpg_settings &st = *V.settings;
+  const int n = a.n, m = a.m, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const double ginv = 1 / I.s.gamma;
+  const int prox = (int)st.proximal;
+  __syncthreads();
+  spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), a.d(), [&](int r, double s) { a.Qd()[r] = prox ? (s + ginv * a.d()[r]) : s; });
+  spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), a.d(), [&](int r, double s) { a.Ad()[r] = s; });
+  __syncthreads();
+  double vm[1] = {0.0}, vs[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = tid; j < n; j += QP_T) { vs[0] += a.d()[j] * a.Qd()[j]; vs[1] += a.d()[j] * a.df()[j]; }
+  /* delta, alpha, s = alpha/delta for the 2m breakpoints; J = L xor P sums */
+  for (int i = tid; i < m; i += QP_T) {
+    const double ss = a.sqrt_sigma()[i], sg = a.sigma()[i], ax = a.Axv()[i], yv = a.y()[i];
+    const double tmp = ss * a.Ad()[i];
+    const double dhi = tmp, dlo = tmp * -1;
+    double t = ax + (-1) * a.bmin()[i]; t = sg * t; t = yv + 1 * t; const double alo = t / ss;
+    t = a.bmax()[i] + (-1) * ax; t = sg * t; t = t + (-1) * yv; const double ahi = t / ss;
+    const double slo = alo / dlo, shi = ahi / dhi;
+    a.ls_delta()[i] = dlo; a.ls_delta()[m + i] = dhi; a.ls_alpha()[i] = alo; a.ls_alpha()[m + i] = ahi;
+    a.ls_key()[i] = slo; a.ls_key()[m + i] = shi;
+    const int Llo = slo > 0, Lhi = shi > 0, Plo = dlo > 0, Phi = dhi > 0;
+    if ((Plo + Llo) == 1) { vs[2] += dlo * dlo; vs[3] += dlo * alo; }
+    if ((Phi + Lhi) == 1) { vs[2] += dhi * dhi; vs[3] += dhi * ahi; }
+  }
+  block_reduce<0, 4>(I.S, vm, vs);
+  const double eta = vs[0], beta = vs[1];
+  const double a0 = eta + vs[2], b0 = beta - vs[3];
+  /* compaction of L = {s > 0} into the sort buffer */
+  int P2 = 1;
+  while (P2 < 2 * m) P2 <<= 1;
+  double *keys; int *idx;
+  if ((size_t)P2 * 12 <= (size_t)V.lds_bytes) { keys = (double *)lds; idx = (int *)(lds + (size_t)P2 * 8); }
+  else { keys = a.ls_key() + 0; idx = a.ls_idx(); /* global fallback: keys are compacted in place below */ }
+  const bool in_lds = ((size_t)P2 * 12 <= (size_t)V.lds_bytes);
+  int nL = 0;
+  {
+    int base = 0;
+    for (int e0 = 0; e0 < 2 * m; e0 += QP_T) {
+      const int e = e0 + tid;
+      const double kv = (e < 2 * m) ? a.ls_key()[e] : 0.0;
+      const int p = (e < 2 * m) && (kv > 0);
+      const unsigned long long bal = __ballot(p);
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int pre = __popcll(bal & below);
+      __syncthreads();
+      if (lane == 0) I.S.ired[wid][2] = __popcll(bal);
+      __syncthreads();
+      int woff = 0, tot = 0;
+      for (int w = 0; w < QP_NW; w++) { if (w < wid) woff += I.S.ired[w][2]; tot += I.S.ired[w][2]; }
+      /* in-place compaction into a.ls_key() is safe: destination index <= source index and every
+       * source of this chunk was read before the barrier above */
+      if (p) { keys[base + woff + pre] = kv; idx[base + woff + pre] = e; }
+      base += tot;
+    }
+    nL = base;
+  }
+  __syncthreads();
+  int P = 1;
+  while (P < nL) P <<= 1;
+  if (P < 2) P = 2;
+  for (int e = nL + tid; e < P; e += QP_T) { keys[e] = 1e300 * 1e300; idx[e] = 0x7fffffff; }
+  __syncthreads();
+  /* bitonic sort ascending by (key, idx) */
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = tid; e < (P >> 1); e += QP_T) {
+        const int i = ((e / j) * (j << 1)) + (e % j), p = i + j;
+        const bool up = ((i & k) == 0);
+        const double ki = keys[i], kp = keys[p];
+        const int ii = idx[i], ip = idx[p];
+        if (ls_greater(ki, ii, kp, ip) == up) { keys[i] = kp; keys[p] = ki; idx[i] = ip; idx[p] = ii; }
+      }
+      __syncthreads();
+    }
+  }
+  /* running (a, b): element i contributes (+d^2, -d*alpha) if delta > 0 else (-d^2, +d*alpha) once
+   * passed; tau = -b/a at the first sorted breakpoint where a*s + b > 0 (linesearch.c:90-118) */
+  const int CH = (nL + QP_T - 1) / QP_T > 0 ? (nL + QP_T - 1) / QP_T : 1;
+  const int e0 = tid * CH, e1 = (e0 + CH < nL) ? e0 + CH : nL;
+  double la = 0.0, lb = 0.0;
+  for (int e = e0; e < e1; e++) {
+    const int iz = idx[e];
+    const double dl = a.ls_delta()[iz], al = a.ls_alpha()[iz];
+    if (dl > 0) { la += dl * dl; lb -= dl * al; } else { la -= dl * dl; lb += dl * al; }
+  }
+  /* exclusive scan of (la, lb) over threads */
+  double ia = la, ib = lb;
+  for (int o = 1; o < 64; o <<= 1) {
+    const double ua = __shfl_up(ia, o), ub = __shfl_up(ib, o);
+    if (lane >= o) { ia += ua; ib += ub; }
+  }
+  __syncthreads();
+  if (lane == 63) { I.scan_a[wid] = ia; I.scan_b[wid] = ib; }
+  __syncthreads();
+  double wa = 0.0, wb = 0.0, ta = 0.0, tb = 0.0;
+  for (int w = 0; w < QP_NW; w++) { if (w < wid) { wa += I.scan_a[w]; wb += I.scan_b[w]; } ta += I.scan_a[w]; tb += I.scan_b[w]; }
+  double ea = __shfl_up(ia, 1), eb = __shfl_up(ib, 1); /* exclusive prefix inside the wavefront */
+  if (lane == 0) { ea = 0.0; eb = 0.0; }
+  double ra = a0 + (wa + ea), rb = b0 + (wb + eb); /* value before my first element */
+  int mypos = 0x7fffffff;
+  double mytau = 0.0;
+  for (int e = e0; e < e1; e++) {
+    if (mypos == 0x7fffffff && ra * keys[e] + rb > 0) { mypos = e; mytau = -rb / ra; }
+    const int iz = idx[e];
+    const double dl = a.ls_delta()[iz], al = a.ls_alpha()[iz];
+    if (dl > 0) { ra = ra + dl * dl; rb = rb - dl * al; } else { ra = ra - dl * dl; rb = rb + dl * al; }
+  }
+  const int pos = block_imin(I.S, mypos);
+  __syncthreads();
+  if (pos == 0x7fffffff) { if (tid == 0) I.S.bc[0] = -(b0 + tb) / (a0 + ta); }
+  else if (mypos == pos) I.S.bc[0] = mytau;
+  __syncthreads();
+  const double tau = I.S.bc[0];
+  if (tid == 0) { I.s.eta = eta; I.s.beta = beta; I.nL = nL; }
+  __syncthreads();
+  (void)in_lds;
+  return tau;
+}
+
+/* =============================================================================================
+ * the loop body of qpalm_solve (src/qpalm.c:484-711) for one QP; runs at most `budget` iterations
+ * =========================================================================================== */
+template <int RPT>
+QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I, char *lds) {
+  const qpg_settings &st = *V.settings;
+  QpArrays a = qp_arrays(V, b);
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * QPG_KMAX * n;
+  __syncthreads();
+  if (tid == 0) I.s = V.sc[b];
+  __syncthreads();
+  if (I.s.done) return;
+  const long long t_launch = QP_CLOCK();
+  if (!I.s.in_solve) { /* qpalm.c:409-482 */
+    if (tid == 0) {
+      I.s.eps_abs_in = st.eps_abs_in; I.s.eps_rel_in = st.eps_rel_in;
+      I.s.reset_newton = 1; I.s.gamma = st.gamma_init; I.s.gamma_maxed = (0 || st.nonconvex);
+    }
+    for (int i = tid; i < m; i += QP_T) a.active_old()[i] = 0;
+    __syncthreads();
+    if (!I.s.initialized) dev_warm_start(V, a, b, 0, 0, I);
+    if (tid == 0) {
+      I.s.dual_objective = 0;
+      I.s.iter = 0; I.s.iter_out = 0; I.s.prev_iter = 0; I.s.no_change = 0;
+      I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
+      I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot;
+    }
+    __syncthreads();
+  }
+  const int scal = I.s.has_scaling, prox = (int)st.proximal;
+  int executed = 0;
+  while (true) {
+    if (I.s.iter >= st.max_iter) { /* qpalm.c:712-735 */
+      dev_store_solution(V, a, b, I);
+      if (tid == 0) { I.s.status = QPG_MAX_ITER_REACHED; I.s.done = 1; I.s.initialized = 0; I.s.in_solve = 0; }
+      break;
+    }
+    if (executed >= budget) break;
+    executed++;
+    QP_OPAQUE(a.b);
+    /* ---- dx-dependent quantities of is_dual_infeasible (termination.c:190-203) -------------- */
+    double vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
+    for (int j = tid; j < n; j += QP_T) {
+      const double dx = a.x()[j] + (-1) * a.x_prev()[j];
+      a.delta_x()[j] = dx;
+      const double t = scal ? a.D()[j] * dx : dx;
+      vm[0] = qmax(vm[0], qabs(t));
+      vs[0] += t * t;
+    }
+    block_reduce<1, 1>(I.S, vm, vs);
+    const double eps_dinf_norm_Ddx = st.eps_dual_inf * vm[0], dxdx = vs[0];
+    /* ---- compute_residuals, m part (iteration.c:26-35) + norms -------------------------------- */
+    for (int k = 0; k < 8; k++) vm[k] = 0.0;
+    for (int k = 0; k < 4; k++) vs[k] = 0.0;
+    double viol = 0.0;
+    for (int i = tid; i < m; i += QP_T) {
+      const double yv = a.y()[i], ax = a.Axv()[i];
+      double t = yv * a.sigma_inv()[i];
+      const double axys = ax + 1 * t;
+      const double zz = qmax(a.bmin()[i], qmin(axys, a.bmax()[i]));
+      const double pr = ax + (-1) * zz;
+      t = pr * a.sigma()[i];
+      const double yhv = yv + 1 * t;
+      a.Axys()[i] = axys; a.z()[i] = zz; a.pri_res()[i] = pr; a.yh()[i] = yhv;
+      const double dy = yhv + (-1) * yv;
+      a.delta_y()[i] = dy;
+      if (scal) {
+        const double Ei = a.E()[i], Einv = a.Einv()[i];
+        vm[0] = qmax(vm[0], qabs(Einv * pr));
+        vm[1] = qmax(vm[1], qabs(Einv * ax));          /* B1: only the Einv.*Ax half */
+        vm[2] = qmax(vm[2], qabs(Ei * dy));
+        vs[0] += (a.bmax()[i] < Ei * QPG_INFTY) ? a.bmax()[i] * qmax(dy, 0) : 0;
+        vs[0] += (a.bmin()[i] > -Ei * QPG_INFTY) ? a.bmin()[i] * qmin(dy, 0) : 0;
+        const double adx = Einv * a.Ad()[i];
+        if ((a.bmax()[i] < Ei * QPG_INFTY && adx >= eps_dinf_norm_Ddx) || (a.bmin()[i] > -Ei * QPG_INFTY && adx <= -eps_dinf_norm_Ddx)) viol = 1.0;
+      } else {
+        vm[0] = qmax(vm[0], qabs(pr));
+        vm[1] = qmax(vm[1], qmax(qabs(ax), qabs(zz)));
+        vm[2] = qmax(vm[2], qabs(dy));
+        vs[0] += (a.bmax()[i] < QPG_INFTY) ? a.bmax()[i] * qmax(dy, 0) : 0;
+        vs[0] += (a.bmin()[i] > -QPG_INFTY) ? a.bmin()[i] * qmin(dy, 0) : 0;
+        const double adx = a.Ad()[i];
+        if ((a.bmax()[i] < QPG_INFTY && adx >= eps_dinf_norm_Ddx) || (a.bmin()[i] > -QPG_INFTY && adx <= -eps_dinf_norm_Ddx)) viol = 1.0;
+      }
+    }
+    vm[3] = viol;
+    __syncthreads();
+    QP_OPAQUE(a.b);
+    /* ---- Atyh = A' yh (iteration.c:45) ------------------------------------------------------- */
+    spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), a.yh(), [&](int r, double s) { a.Atyh()[r] = s; });
+    __syncthreads();
+    /* ---- df, dphi (iteration.c:37-47) + dual residual norms (termination.c:61-129) ---------- */
+    const double gam = I.s.gamma;
+    const double mginv = -1 / gam, tg = -I.s.tau / gam;
+    for (int j = tid; j < n; j += QP_T) {
+      const double atyh = a.Atyh()[j];
+      double dfv = a.Qxv()[j] + 1 * a.q()[j];
+      if (prox) dfv = dfv + mginv * a.x0()[j];
+      const double dphi = dfv + 1 * atyh;
+      a.df()[j] = dfv; a.dphi()[j] = dphi;
+      const double Dinv = scal ? a.Dinv()[j] : 1.0;
+      double r1, r2;
+      if (prox) {
+        const double xx0 = a.x()[j] + (-1) * a.x0()[j];
+        const double tn = dphi + mginv * xx0;
+        r1 = scal ? Dinv * tn : tn;
+        r2 = scal ? Dinv * dphi : dphi;
+      } else { r1 = scal ? Dinv * dphi : dphi; r2 = r1; }
+      vm[4] = qmax(vm[4], qabs(r1));
+      vm[5] = qmax(vm[5], qabs(r2));
+      const double nq = scal ? Dinv * a.Qxv()[j] : a.Qxv()[j], nqq = scal ? Dinv * a.q()[j] : a.q()[j], na = scal ? Dinv * atyh : atyh;
+      vm[6] = qmax(vm[6], qmax(qabs(nq), qmax(qabs(nqq), qabs(na))));
+      double atdy = atyh + (-1) * a.Aty()[j];
+      if (scal) atdy = Dinv * atdy;
+      vm[7] = qmax(vm[7], qabs(atdy));
+      const double dx = a.delta_x()[j];
+      if (prox) { const double tq = a.Qd()[j] + tg * a.d()[j]; vs[1] += dx * tq; } else vs[1] += a.Qd()[j] * dx;
+      vs[2] += a.q()[j] * dx;
+    }
+    block_reduce<8, 3>(I.S, vm, vs);
+    /* ---- decision: check_termination + the branch of qpalm.c:488-676 ------------------------- */
+    if (tid == 0) {
+      qpg_scalars &s = I.s;
+      s.pri_res_norm = vm[0];
+      s.dua_res_norm = vm[4]; s.dua2_res_norm = vm[5];
+      if (scal) { s.dua_res_norm *= s.sc_cinv; s.dua2_res_norm *= s.sc_cinv; }
+      s.eps_pri = st.eps_abs + st.eps_rel * vm[1];
+      double mx = vm[6];
+      if (scal) mx *= s.sc_cinv;
+      s.eps_dua = st.eps_abs + st.eps_rel * mx;
+      s.eps_dua_in = s.eps_abs_in + s.eps_rel_in * mx;
+      int kind;
+      const double eps_pinf = st.eps_prim_inf * vm[2];
+      int prim_inf = 0, dual_inf = 0;
+      if (eps_pinf != 0) prim_inf = (vm[7] <= eps_pinf) && (vs[0] <= -eps_pinf);
+      if (eps_dinf_norm_Ddx != 0 && vm[3] == 0.0) {
+        const double dxQdx = vs[1], qdx = vs[2], e2 = st.eps_dual_inf * st.eps_dual_inf;
+        if (scal) dual_inf = (dxQdx <= -s.sc_c * e2 * dxdx) || ((dxQdx <= s.sc_c * e2 * dxdx) && (qdx <= -s.sc_c * eps_dinf_norm_Ddx));
+        else dual_inf = (dxQdx <= -e2 * dxdx) || ((dxQdx <= e2 * dxdx) && (qdx <= -eps_dinf_norm_Ddx));
+      }
+      if ((s.pri_res_norm < s.eps_pri) && (s.dua_res_norm < s.eps_dua)) { s.status = QPG_SOLVED; kind = QP_KIND_TERMINATED; }
+      else if (prim_inf) { s.status = QPG_PRIMAL_INFEASIBLE; kind = QP_KIND_TERMINATED; }
+      else if (dual_inf) { s.status = QPG_DUAL_INFEASIBLE; kind = QP_KIND_TERMINATED; }
+      else if ((s.dua2_res_norm <= s.eps_dua_in) || (s.no_change == 3)) kind = QP_KIND_OUTER;
+      else if (s.iter == s.prev_iter + (int)st.inner_max_iter) kind = QP_KIND_FORCED;
+      else kind = QP_KIND_NEWTON;
+      I.kind = kind;
+    }
+    __syncthreads();
+    QP_OPAQUE(a.b);
+    const int kind = I.kind;
+    if (kind == QP_KIND_TERMINATED) {
+      const int status = I.s.status;
+      if (status == QPG_SOLVED) dev_store_solution(V, a, b, I);
+      else if (status == QPG_PRIMAL_INFEASIBLE) {
+        if (scal) for (int i = tid; i < m; i += QP_T) { double v = a.delta_y()[i] * I.s.sc_cinv; a.delta_y()[i] = a.E()[i] * v; }
+      } else {
+        if (scal) for (int j = tid; j < n; j += QP_T) a.delta_x()[j] = a.D()[j] * a.delta_x()[j];
+      }
+      __syncthreads();
+      if (tid == 0) { I.s.done = 1; I.s.initialized = 0; I.s.in_solve = 0; I.s.last_kind = QP_KIND_TERMINATED; }
+      break;
+    }
+    if (kind == QP_KIND_OUTER) {
+      if (tid == 0) I.s.no_change = 0;
+      __syncthreads();
+      if (I.s.iter_out > 0 && I.s.pri_res_norm > I.s.eps_pri) dev_update_sigma<RPT>(V, a, b, I, L, Dg, Wst, lds);
+      for (int i = tid; i < m; i += QP_T) a.y()[i] = a.yh()[i];
+      for (int j = tid; j < n; j += QP_T) a.Aty()[j] = a.Atyh()[j];
+      __syncthreads();
+      if (tid == 0) {
+        I.s.eps_abs_in = qmax(st.eps_abs, st.rho * I.s.eps_abs_in);
+        I.s.eps_rel_in = qmax(st.eps_rel, st.rho * I.s.eps_rel_in);
+      }
+      __syncthreads();
+      if (prox) { /* qpalm.c:612-630 (convex) */
+        if (!I.s.gamma_maxed && I.s.iter_out > 0 && I.s.nb_enter == 0 && I.s.nb_leave == 0 && I.s.pri_res_norm < I.s.eps_pri) {
+          for (int i = tid; i < m; i += QP_T) { const double t = a.y()[i] / a.sigma()[i]; a.Axys()[i] = a.Axv()[i] + 1 * t; } /* B3 */
+          __syncthreads();
+          dev_active_sets(a, I);
+          if (I.s.nb_enter == 0 && I.s.nb_leave == 0) dev_boost_gamma(V, a, b, I, L, lds);
+          else dev_update_gamma(V, a, I);
+        } else dev_update_gamma(V, a, I);
+        for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
+      }
+      for (int i = tid; i < m; i += QP_T) a.pri_res_in()[i] = a.pri_res()[i];
+      __syncthreads();
+      if (tid == 0) { I.s.iter_out++; I.s.prev_iter = I.s.iter; I.s.last_kind = QP_KIND_OUTER; I.s.last_fact = 0; }
+    } else if (kind == QP_KIND_FORCED) { /* qpalm.c:647-660 */
+      if (tid == 0) I.s.no_change = 0;
+      __syncthreads();
+      if (I.s.iter_out > 0 && I.s.pri_res_norm > I.s.eps_pri) dev_update_sigma<RPT>(V, a, b, I, L, Dg, Wst, lds);
+      if (prox) {
+        dev_update_gamma(V, a, I);
+        if (!st.nonconvex) for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
+      }
+      for (int i = tid; i < m; i += QP_T) a.pri_res_in()[i] = a.pri_res()[i];
+      __syncthreads();
+      if (tid == 0) { I.s.iter_out++; I.s.prev_iter = I.s.iter; I.s.last_kind = QP_KIND_FORCED; I.s.last_fact = 0; }
+    } else { /* Newton step, qpalm.c:662-668 -> update_primal_iterate (iteration.c:213-229) */
+      if (tid == 0) {
+        if (I.s.nb_enter + I.s.nb_leave) I.s.no_change = 0; else I.s.no_change++;
+        if (((I.s.iter % (int)st.reset_newton_iter) + (int)st.reset_newton_iter) % (int)st.reset_newton_iter == 0) I.s.reset_newton = 1;
+      }
+      __syncthreads();
+      dev_active_sets(a, I);
+      /* newton_set_direction, SCHUR branch (newton.c:96-113) */
+      const int nchange = I.s.nb_enter + I.s.nb_leave;
+      const double thr = qmin(st.max_rank_update_fraction * (double)(n + m), (double)st.max_rank_update);
+      int action;
+      if ((I.s.reset_newton && I.s.nb_active) || ((double)nchange > thr) ||
+          (V.update_rank_threshold >= 0 && I.s.nb_active && nchange > V.update_rank_threshold)) action = 1;
+      else if (I.s.nb_active) action = nchange ? 2 : 0;
+      else action = 3;
+      QP_OPAQUE(a.b);
+      const long long t0 = QP_CLOCK();
+      if (action == 1) {
+        form_schur<false>(V, b, L, true, prox != 0, gam, I.S, lds);
+        dev_factor<RPT>(V, L, Dg, lds);
+      } else if (action == 3) {
+        form_schur<false>(V, b, L, false, prox != 0, gam, I.S, lds);
+        dev_factor<RPT>(V, L, Dg, lds);
+      } else if (action == 2) {
+        dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), I.s.nb_leave, I.S, lds);
+      }
+      const long long t1 = QP_CLOCK();
+      QP_OPAQUE(a.b);
+      /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
+      for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
+      __syncthreads();
+      dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes);
+      const long long t2 = QP_CLOCK();
+      for (int i = tid; i < m; i += QP_T) a.active_old()[i] = a.active()[i];
+      if (tid == 0) {
+        I.s.reset_newton = 0;
+        if (action == 1) { I.s.n_refactor++; I.s.ticks_factor += t1 - t0; }
+        if (action == 3) { I.s.n_factor_Q++; I.s.ticks_factor += t1 - t0; }
+        if (action == 2) { I.s.n_rank1 += nchange; I.s.n_sweeps += (nchange + 15) / 16; I.s.ticks_update += t1 - t0; }
+        I.s.n_solve++; I.s.ticks_solve += t2 - t1;
+        I.s.last_fact = action;
+      }
+      QP_OPAQUE(a.b);
+      const double tau = dev_linesearch(V, a, I, lds);
+      const long long t3 = QP_CLOCK();
+      QP_OPAQUE(a.b);
+      /* iteration.c:219-228 */
+      for (int j = tid; j < n; j += QP_T) {
+        const double xv = a.x()[j];
+        a.x_prev()[j] = xv;
+        a.dphi_prev()[j] = a.dphi()[j];
+        a.x()[j] = xv + tau * a.d()[j];
+        const double qd = a.Qd()[j] * tau;
+        a.Qd()[j] = qd;
+        a.Qxv()[j] = a.Qxv()[j] + 1 * qd;
+      }
+      for (int i = tid; i < m; i += QP_T) {
+        const double ad = a.Ad()[i] * tau;
+        a.Ad()[i] = ad;
+        a.Axv()[i] = a.Axv()[i] + 1 * ad;
+      }
+      if (tid == 0) { I.s.tau = tau; I.s.last_kind = QP_KIND_NEWTON; I.s.ticks_linesearch += t3 - t2; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      I.s.iter++;
+      /* time limit (qpalm.c:680-710): wall_clock64 ticks at 100 MHz */
+      const double elapsed = (double)(QP_CLOCK() - t_launch) * 1e-8;
+      if (I.s.setup_time + I.s.solve_time + elapsed > st.time_limit) I.kind = -1; else I.kind = 0;
+    }
+    __syncthreads();
+    if (I.kind == -1) {
+      if (tid == 0) { I.s.iter--; }
+      __syncthreads();
+      dev_store_solution(V, a, b, I);
+      if (tid == 0) { I.s.status = QPG_TIME_LIMIT_REACHED; I.s.done = 1; I.s.initialized = 0; I.s.in_solve = 0; }
+      break;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    I.s.solve_time += (double)(QP_CLOCK() - t_launch) * 1e-8;
+    I.s.ticks_total += QP_CLOCK() - t_launch;
+    V.sc[b] = I.s;
+  }
+  __syncthreads();
+}
+
+#endif

@@ -1,0 +1,87 @@
+/*
+ * qpalm_types.h -- plain-data structures shared by the host C-ABI layer and the gfx950 kernels.
+ *
+ * Device layout (HBM): a "batch" holds B independent QPs of identical dimensions (n, m).  Every
+ * named vector of the reference's QPALMWorkspace (include/types.h:197-314) is one [B][n] or [B][m]
+ * fp64 array, QP-major, so that the workgroup that owns QP b streams contiguous, coalesced rows.
+ * Indices are int32 on the device (n, m, nnz < 2^31); the C-ABI takes the reference's 64-bit c_int.
+ */
+#ifndef QPALM_TYPES_H_GFX950
+#define QPALM_TYPES_H_GFX950
+
+#include <stdint.h>
+
+/* status codes, include/constants.h:30-37 */
+#define QPG_SOLVED 1
+#define QPG_DUAL_TERMINATED 2
+#define QPG_MAX_ITER_REACHED (-2)
+#define QPG_PRIMAL_INFEASIBLE (-3)
+#define QPG_DUAL_INFEASIBLE (-4)
+#define QPG_TIME_LIMIT_REACHED (-5)
+#define QPG_UNSOLVED (-10)
+#define QPG_ERROR 0
+#define QPG_INFTY 1e20
+
+/* == QPALMSettings (include/types.h:119-150), c_int = 64-bit */
+typedef struct {
+  int64_t max_iter, inner_max_iter;
+  double eps_abs, eps_rel, eps_abs_in, eps_rel_in, rho, eps_prim_inf, eps_dual_inf, theta, delta, sigma_max,
+      sigma_init;
+  int64_t proximal;
+  double gamma_init, gamma_upd, gamma_max;
+  int64_t scaling, nonconvex, verbose, print_iter, warm_start, reset_newton_iter, enable_dual_termination;
+  double dual_objective_limit, time_limit;
+  int64_t ordering, factorization_method, max_rank_update;
+  double max_rank_update_fraction;
+} qpg_settings;
+
+/* per-QP scalar state: everything qpalm_solve keeps in locals or in QPALMWorkspace scalars
+ * (src/qpalm.c:401-482, include/types.h:197-314), so that a solve can be suspended after any
+ * iteration and resumed by a later launch. */
+typedef struct {
+  double gamma, tau, eta, beta;
+  double eps_pri, eps_dua, eps_dua_in, eps_abs_in, eps_rel_in, eps_k_abs, eps_k_rel;
+  double sqrt_sigma_max, sqrt_delta, sc_c, sc_cinv;
+  double pri_res_norm, dua_res_norm, dua2_res_norm, objective, dual_objective;
+  double setup_time, solve_time;
+  int32_t iter, iter_out, prev_iter, no_change;
+  int32_t status, done, initialized, gamma_maxed, reset_newton, in_solve;
+  int32_t nb_active, nb_enter, nb_leave, nb_sigma_changed;
+  int32_t last_kind, last_fact, slot, has_scaling;
+  /* work counters (device side statistics for the roofline accounting in bench.py) */
+  int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_spmv;
+  int64_t ticks_total, ticks_factor, ticks_update, ticks_solve, ticks_linesearch, ticks_resid;
+} qpg_scalars;
+
+/* view of one batch in device memory; passed by value to the kernels */
+typedef struct {
+  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, pad1;
+  /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.
+   * Q: lower CSC.  Qf: both triangles (row == column compressed), with permutation into Q. */
+  int32_t *Ap, *Ai, *Atp, *Ati, *Atperm, *Qp, *Qi, *Qfp, *Qfi, *Qfperm;
+  double *Ax, *Atx, *Atss, *Qx, *Qfx;
+  double *q, *bmin, *bmax, *c0;
+  /* iterates / work vectors */
+  double *x, *y, *Axv, *Qxv, *Aty, *x_prev, *x0;
+  double *sigma, *sigma_inv, *sqrt_sigma, *At_scale;
+  double *Axys, *z, *pri_res, *pri_res_in, *yh, *Atyh, *df, *dphi, *dphi_prev, *d, *Qd, *Ad;
+  double *delta_y, *delta_x, *temp_n, *temp_m;
+  double *D, *Dinv, *E, *Einv;
+  double *ls_key;       /* [B][2m] line-search keys (global fallback / scratch) */
+  int32_t *ls_idx;      /* [B][2m] */
+  double *ls_delta, *ls_alpha; /* [B][2m] */
+  int32_t *active, *active_old, *enter, *leave; /* [B][m] */
+  double *sol_x, *sol_y;
+  /* factor slots */
+  double *L;   /* [nslots][ld*n] column-major, unit lower, strict lower part used */
+  double *Dg;  /* [nslots][n] */
+  double *Wst; /* [nslots][QPG_KMAX][n] staging for rank-update vectors */
+  double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
+  qpg_scalars *sc; /* [B] */
+  qpg_settings *settings; /* [1] */
+  int32_t *queue; /* [4] work-queue head etc. */
+} qpg_view;
+
+#define QPG_KMAX 16
+
+#endif

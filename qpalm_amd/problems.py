@@ -1,0 +1,113 @@
+"""Synthetic QP generators for the configurations of BASELINE.json.
+
+The MATLAB generators of the reference are the model (simulations/randomQP.m:32-38,
+examples/qpalm_mex_demo.m:4-10, simulations/randomMPC.m:24-28,87-121); data sets themselves
+are not in the reference tree.  Everything is seeded (PCG64) so CPU and GPU legs see the same
+inputs.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import scipy.sparse as sp
+
+
+@dataclass
+class QP:
+    """minimize 1/2 x'Qx + q'x + c  s.t. bmin <= Ax <= bmax.  Q: CSC, lower triangle only."""
+    n: int
+    m: int
+    Qp: np.ndarray
+    Qi: np.ndarray
+    Qx: np.ndarray
+    Ap: np.ndarray
+    Ai: np.ndarray
+    Ax: np.ndarray
+    q: np.ndarray
+    bmin: np.ndarray
+    bmax: np.ndarray
+    c: float = 0.0
+
+    def args(self):
+        return (self.n, self.m, self.Qp, self.Qi, self.Qx, self.Ap, self.Ai, self.Ax, self.q, self.bmin, self.bmax)
+
+    def Q_full(self):
+        L = sp.csc_matrix((self.Qx, self.Qi, self.Qp), shape=(self.n, self.n))
+        L = sp.tril(L)
+        return (L + sp.tril(L, -1).T).tocsc()
+
+    def A_mat(self):
+        return sp.csc_matrix((self.Ax, self.Ai, self.Ap), shape=(self.m, self.n))
+
+
+def _csc(M):
+    M = sp.csc_matrix(M)
+    M.sort_indices()
+    M.sum_duplicates()
+    return M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.astype(np.float64)
+
+
+def random_qp(n=1000, m=2000, density_A=0.01, density_M=0.005, seed=1000):
+    """cfg2 "random-1000": A = sprandn(m,n,dA); Q = (M+M')/2 + diag(rowsum|.|+1), M = sprandn(n,n,dM);
+    q ~ N(0,1); bmin = -U(0,1); bmax = U(0,1)   (BASELINE.md section 3)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    A = sp.random(m, n, density=density_A, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    M = sp.random(n, n, density=density_M, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    S = ((M + M.T) * 0.5).tocsc()
+    rowsum = np.asarray(abs(S).sum(axis=1)).ravel()
+    Qf = (S + sp.diags(rowsum + 1.0)).tocsc()
+    Ql = sp.tril(Qf).tocsc()
+    q = rng.standard_normal(n)
+    bmin = -rng.random(m)
+    bmax = rng.random(m)
+    Qp, Qi, Qx = _csc(Ql)
+    Ap, Ai, Ax = _csc(A)
+    return QP(n, m, Qp, Qi, Qx, Ap, Ai, Ax, q, bmin, bmax)
+
+
+def random_mpc_qp(T=10, nx=10, nu=5, seed=0, x_init_scale=1.0, x_init=None):
+    """cfg3 "mpc-160": non-condensed MPC QP modelled on simulations/randomMPC.m:24-28,87-121 with a
+    fixed terminal box instead of the MPT invariant set (no MPT here).  n = (T+1)nx + T nu,
+    rows: nx(T+1) dynamics equalities (incl. x_0 = x_init), then box rows on every state and input."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Adyn = sp.random(nx, nx, density=1.0, random_state=rng, data_rvs=rng.standard_normal).toarray()
+    Adyn = 0.5 * (Adyn + Adyn.T)
+    Adyn = 1.0 * Adyn / max(1.0, np.max(np.abs(np.linalg.eigvals(Adyn)))) * 1.02
+    Bdyn = rng.standard_normal((nx, nu))
+    Mq = 5 * sp.random(nx, nx, density=0.5, random_state=rng, data_rvs=rng.standard_normal).toarray()
+    Qs = Mq @ Mq.T
+    R = 0.01 * np.eye(nu)
+    xb = 10 + 2 * rng.random(nx)
+    ub = 10 + 2 * rng.random(nu)
+    n = (T + 1) * nx + T * nu
+    blocks = [Qs] * T + [Qs] + [R] * T
+    Qf = sp.block_diag(blocks, format="csc")
+    # dynamics: x_{k+1} - A x_k - B u_k = 0 ; x_0 = x_init
+    rows = []
+    E0 = sp.hstack([sp.eye(nx), sp.csc_matrix((nx, n - nx))])
+    rows.append(E0)
+    for k in range(T):
+        r = sp.lil_matrix((nx, n))
+        r[:, k * nx:(k + 1) * nx] = -Adyn
+        r[:, (k + 1) * nx:(k + 2) * nx] = np.eye(nx)
+        r[:, (T + 1) * nx + k * nu:(T + 1) * nx + (k + 1) * nu] = -Bdyn
+        rows.append(r.tocsc())
+    Aeq = sp.vstack(rows)
+    Abox = sp.eye(n, format="csc")
+    A = sp.vstack([Aeq, Abox]).tocsc()
+    if x_init is None:
+        x_init = x_init_scale * (2 * rng.random(nx) - 1) * 2.0
+    beq = np.concatenate([x_init, np.zeros(T * nx)])
+    box = np.concatenate([np.tile(xb, T + 1), np.tile(ub, T)])
+    bmin = np.concatenate([beq, -box])
+    bmax = np.concatenate([beq, box])
+    q = np.zeros(n)
+    Qp, Qi, Qx = _csc(sp.tril(Qf))
+    Ap, Ai, Ax = _csc(A)
+    return QP(n, A.shape[0], Qp, Qi, Qx, Ap, Ai, Ax, q, bmin, bmax)
+
+
+def fixture_qp(p):
+    """QP from a tests/golden/reference_tests.json problem dict."""
+    return QP(p["n"], p["m"], np.array(p["Qp"], np.int64), np.array(p["Qi"], np.int64), np.array(p["Qx"], float),
+              np.array(p["Ap"], np.int64), np.array(p["Ai"], np.int64), np.array(p["Ax"], float),
+              np.array(p["q"], float), np.array(p["bmin"], float), np.array(p["bmax"], float), float(p.get("c", 0.0)))

@@ -1,0 +1,279 @@
+"""Host-side mirror of the reference's Python interface on top of the gfx950 C ABI.
+
+`Qpalm` mirrors interfaces/python/qpalm.py:192-375 (set_default_settings / set_data / _allocate_work ==
+qpalm_setup / _solve / _warm_start / _update_bounds / _update_q) for ONE QP; `QpalmBatch` is the
+batched form the MI355X engine is built for (B independent QPs of equal dimensions resident in HBM).
+Neither class contains numerics: everything runs in the HIP kernels behind include/qpalm_gfx950.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import Info, QpgError, Settings, Stats, f64, fptr, i64, iptr
+
+SOLVED, DUAL_TERMINATED, MAX_ITER_REACHED = 1, 2, -2
+PRIMAL_INFEASIBLE, DUAL_INFEASIBLE, TIME_LIMIT_REACHED, UNSOLVED, ERROR = -3, -4, -5, -10, 0
+
+
+class Context:
+    def __init__(self, device=0, lib_path=None, **options):
+        self.L = capi.load(lib_path)
+        h = C.c_void_p()
+        rc = self.L.qpg_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise QpgError(rc, self.L.qpg_last_error().decode())
+        self.h = h
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        rc = self.L.qpg_ctx_set_option(self.h, name.encode(), int(value))
+        if rc != 0:
+            raise QpgError(rc, self.L.qpg_last_error().decode())
+
+    @property
+    def backend(self):
+        return self.L.qpg_backend_name().decode()
+
+    def default_settings(self, **kw):
+        s = Settings()
+        self.L.qpg_set_default_settings(C.byref(s))
+        for k, v in kw.items():
+            if not hasattr(s, k):
+                raise AttributeError(k)
+            setattr(s, k, v)
+        return s
+
+    def close(self):
+        if self.h:
+            self.L.qpg_ctx_destroy(self.h)
+            self.h = None
+
+
+class QpalmBatch:
+    """B QPs  min 1/2 x'Qx + q'x + c  s.t. bmin <= Ax <= bmax  with common (n, m)."""
+
+    def __init__(self, ctx, problems, settings=None):
+        """problems: sequence of objects with .args() -> (n, m, Qp, Qi, Qx, Ap, Ai, Ax, q, bmin, bmax) and .c"""
+        self.ctx, self.L = ctx, ctx.L
+        self.B = len(problems)
+        p0 = problems[0]
+        self.n, self.m = int(p0.n), int(p0.m)
+        nnzA = max(int(p.Ap[-1]) for p in problems)
+        nnzQ = max(int(p.Qp[-1]) for p in problems)
+        self.settings = settings if settings is not None else ctx.default_settings()
+        h = C.c_void_p()
+        self._check(self.L.qpg_batch_create(ctx.h, self.B, self.n, self.m, nnzA, nnzQ, C.byref(self.settings), C.byref(h)))
+        self.h = h
+        for b, p in enumerate(problems):
+            if p.n != self.n or p.m != self.m:
+                raise ValueError("all QPs of a batch must share (n, m)")
+            Qp, Qi, Qx, Ap, Ai, Ax = i64(p.Qp), i64(p.Qi), f64(p.Qx), i64(p.Ap), i64(p.Ai), f64(p.Ax)
+            q, bmin, bmax = f64(p.q), f64(p.bmin), f64(p.bmax)
+            self._check(self.L.qpg_batch_set_problem(self.h, b, iptr(Qp), iptr(Qi), fptr(Qx), iptr(Ap), iptr(Ai), fptr(Ax),
+                                                     fptr(q), float(getattr(p, "c", 0.0)), fptr(bmin), fptr(bmax)))
+        self._check(self.L.qpg_batch_setup(self.h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise QpgError(rc, self.L.qpg_last_error().decode())
+
+    # -- qpalm.h API ---------------------------------------------------------------------------
+    def warm_start(self, x=None, y=None):
+        xs = f64(x).reshape(self.B, self.n) if x is not None else None
+        ys = f64(y).reshape(self.B, self.m) if y is not None else None
+        self._check(self.L.qpg_batch_warm_start(self.h, fptr(xs) if xs is not None else None, fptr(ys) if ys is not None else None))
+
+    def solve(self):
+        self._check(self.L.qpg_batch_solve(self.h))
+
+    def iterate(self, k=1):
+        self._check(self.L.qpg_batch_iterate(self.h, int(k)))
+
+    def num_unfinished(self):
+        c = capi.c_int(0)
+        self._check(self.L.qpg_batch_num_unfinished(self.h, C.byref(c)))
+        return int(c.value)
+
+    def update_settings(self, s):
+        rc = self.L.qpg_batch_update_settings(self.h, C.byref(s))
+        if rc == 0:
+            self.settings = s
+        return rc
+
+    def update_bounds(self, bmin=None, bmax=None):
+        a = f64(bmin).reshape(self.B, self.m) if bmin is not None else None
+        b = f64(bmax).reshape(self.B, self.m) if bmax is not None else None
+        return self.L.qpg_batch_update_bounds(self.h, fptr(a) if a is not None else None, fptr(b) if b is not None else None)
+
+    def update_q(self, q):
+        q = f64(q).reshape(self.B, self.n)
+        self._check(self.L.qpg_batch_update_q(self.h, fptr(q)))
+
+    # -- results --------------------------------------------------------------------------------
+    def info(self, b=0):
+        out = Info()
+        self._check(self.L.qpg_batch_get_info(self.h, int(b), C.byref(out)))
+        return out
+
+    def stats(self, b=0):
+        out = Stats()
+        self._check(self.L.qpg_batch_get_stats(self.h, int(b), C.byref(out)))
+        return out
+
+    def solution(self):
+        x, y = np.zeros((self.B, self.n)), np.zeros((self.B, self.m))
+        self._check(self.L.qpg_batch_get_solution(self.h, fptr(x), fptr(y)))
+        return x, y
+
+    def statuses(self):
+        return np.array([int(self.info(b).status_val) for b in range(self.B)])
+
+    _LEN_N = {"x", "Qx", "Aty", "x_prev", "x0", "Atyh", "df", "dphi", "dphi_prev", "d", "Qd", "delta_x", "temp_n", "D", "Dinv",
+              "solution_x", "q"}
+
+    def _veclen(self, name):
+        if name in self._LEN_N:
+            return self.n
+        if name in ("delta", "alpha"):
+            return 2 * self.m
+        return self.m
+
+    def vec(self, name, b=0):
+        out = np.zeros(self._veclen(name))
+        self._check(self.L.qpg_batch_get_vector(self.h, name.encode(), int(b), fptr(out), len(out)))
+        return out
+
+    def set_vec(self, name, v, b=0):
+        v = f64(v)
+        self._check(self.L.qpg_batch_set_vector(self.h, name.encode(), int(b), fptr(v), len(v)))
+
+    def ivec(self, name, b=0, length=None):
+        out = np.zeros(self.m if length is None else int(length), np.int64)
+        if len(out):
+            self._check(self.L.qpg_batch_get_ivector(self.h, name.encode(), int(b), iptr(out), len(out)))
+        return out
+
+    def set_ivec(self, name, v, b=0):
+        v = i64(v)
+        if len(v):
+            self._check(self.L.qpg_batch_set_ivector(self.h, name.encode(), int(b), iptr(v), len(v)))
+
+    def set_scalar(self, name, v, b=0):
+        self._check(self.L.qpg_batch_set_scalar(self.h, name.encode(), int(b), float(v)))
+
+    def factor(self, b=0):
+        Lm, D = np.zeros((self.n, self.n)), np.zeros(self.n)
+        self._check(self.L.qpg_batch_get_factor(self.h, int(b), fptr(Lm), fptr(D), self.n))
+        return Lm.T.copy(), D  # column-major buffer -> [i, j]
+
+    # -- solver_interface.h surface ---------------------------------------------------------------
+    def mat_vec(self, which, x, b=0):
+        x = f64(x)
+        y = np.zeros(self.m if which == "A" else self.n)
+        self._check(self.L.qpg_mat_vec(self.h, int(b), ord(which), fptr(x), fptr(y)))
+        return y
+
+    def mat_tpose_vec(self, which, x, b=0):
+        x = f64(x)
+        y = np.zeros(self.n)
+        self._check(self.L.qpg_mat_tpose_vec(self.h, int(b), ord(which), fptr(x), fptr(y)))
+        return y
+
+    def op(self, name, b=0):
+        self._check(getattr(self.L, "qpg_" + name)(self.h, int(b)))
+
+    def exact_linesearch(self, b=0):
+        t = capi.c_float(0.0)
+        self._check(self.L.qpg_exact_linesearch(self.h, int(b), C.byref(t)))
+        return float(t.value)
+
+    def ldlsolve_all(self, reps=1):
+        ms = C.c_float(0.0)
+        self._check(self.L.qpg_batch_ldlsolve_all(self.h, int(reps), C.byref(ms)))
+        return float(ms.value)
+
+    def device_ptr(self, name):
+        p, nbytes = C.c_void_p(), C.c_size_t(0)
+        self._check(self.L.qpg_batch_device_ptr(self.h, name.encode(), C.byref(p), C.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qpg_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Qpalm:
+    """Single-QP facade with the reference's Python class shape (interfaces/python/qpalm.py:192-375)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.settings = ctx.default_settings()
+        self._prob = None
+        self._batch = None
+
+    def set_default_settings(self):
+        self.settings = self.ctx.default_settings()
+
+    def set_data(self, Q, A, q, bmin, bmax, c=0.0):
+        """Q, A: scipy sparse (any format); only tril(Q) is read, like stype = -1."""
+        import scipy.sparse as sp
+        from .problems import QP
+        Qc = sp.csc_matrix(sp.tril(sp.csc_matrix(Q)))
+        Ac = sp.csc_matrix(A)
+        Qc.sort_indices()
+        Ac.sort_indices()
+        self._prob = QP(Ac.shape[1], Ac.shape[0], Qc.indptr.astype(np.int64), Qc.indices.astype(np.int64),
+                        Qc.data.astype(float), Ac.indptr.astype(np.int64), Ac.indices.astype(np.int64),
+                        Ac.data.astype(float), f64(q), f64(bmin), f64(bmax), float(c))
+
+    def set_problem(self, prob):
+        self._prob = prob
+
+    def setup(self):
+        self._batch = QpalmBatch(self.ctx, [self._prob], self.settings)
+        return self
+
+    def warm_start(self, x=None, y=None):
+        self._batch.warm_start(None if x is None else f64(x)[None, :], None if y is None else f64(y)[None, :])
+
+    def solve(self):
+        self._batch.solve()
+        return self.info
+
+    def update_settings(self, s):
+        return self._batch.update_settings(s)
+
+    def update_bounds(self, bmin=None, bmax=None):
+        return self._batch.update_bounds(None if bmin is None else f64(bmin)[None, :], None if bmax is None else f64(bmax)[None, :])
+
+    def update_q(self, q):
+        self._batch.update_q(f64(q)[None, :])
+
+    @property
+    def info(self):
+        return self._batch.info(0)
+
+    @property
+    def status_val(self):
+        return int(self.info.status_val)
+
+    @property
+    def x(self):
+        return self._batch.solution()[0][0]
+
+    @property
+    def y(self):
+        return self._batch.solution()[1][0]
+
+    @property
+    def batch(self):
+        return self._batch

@@ -17,3 +17,33 @@ def pytest_configure(config):
 def golden():
     with open(os.path.join(ROOT, "tests", "golden", "reference_tests.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """TEST-ONLY host build of the kernel source (tests/emu); never used by the product."""
+    from qpalm_amd import build
+    return build.build_emu()
+
+
+_CTX = {}
+
+
+@pytest.fixture(params=[pytest.param("emu", id="emu"), pytest.param("hip", marks=pytest.mark.gpu, id="hip")])
+def ctx(request):
+    """A backend context: 'emu' = kernel source emulated on the host (CPU tests),
+    'hip' = the shipped gfx950 library on a real MI355X (the parity tests proper)."""
+    from qpalm_amd.solver import Context
+    kind = request.param
+    if kind not in _CTX:
+        if kind == "emu":
+            _CTX[kind] = Context(0, lib_path=request.getfixturevalue("emu_lib"))
+            assert _CTX[kind].backend == "host-emulation"
+        else:
+            _CTX[kind] = Context(0)
+            assert _CTX[kind].backend == "gfx950-hip"
+    c = _CTX[kind]
+    c.kind = kind
+    c.set_option("update_rank_threshold", -1)
+    c.set_option("max_slots", 512)
+    return c

@@ -1,0 +1,34 @@
+/*
+ * qpalm_emu.cpp -- TEST-ONLY build of the kernel source + C ABI on the host (see hip_emu.h).
+ * Never loaded by the product; qpg_backend_name() returns "host-emulation" so that tests can tell
+ * the two libraries apart.
+ */
+#include "hip_emu.h"
+
+#include <chrono>
+#include <string>
+
+#include "../../qpalm_amd/csrc/qpalm_kernels.h"
+
+static std::string g_rt_err;
+static int rt_device_init(int, std::string &) { return 0; }
+static int rt_malloc(void **pp, size_t bytes) { *pp = calloc(bytes ? bytes : 1, 1); return *pp ? 0 : 1; }
+
+#define RT_BACKEND_NAME "host-emulation"
+#define RT_DEVICE_INIT(device, why) rt_device_init((device), (why))
+#define RT_MALLOC(pp, bytes) rt_malloc((void **)(pp), (bytes))
+#define RT_FREE(p) free(p)
+#define RT_MEMCPY_H2D(dst, src, bytes) memcpy((void *)(dst), (const void *)(src), (bytes))
+#define RT_MEMCPY_D2H(dst, src, bytes) memcpy((void *)(dst), (const void *)(src), (bytes))
+#define RT_MEMSET(dst, val, bytes) memset((void *)(dst), (val), (bytes))
+#define RT_SYNC() 0
+#define RT_LAST_ERROR() (g_rt_err.c_str())
+#define RT_LAUNCH(kernel, grid, block, shmem, ...) emu::launch(kernel, emu_dim3(grid), emu_dim3(block), (shmem), __VA_ARGS__)
+#define RT_TIMED_LAUNCH(ms, kernel, grid, block, shmem, ...)                                   \
+  do {                                                                                         \
+    auto t0_ = std::chrono::steady_clock::now();                                               \
+    emu::launch(kernel, emu_dim3(grid), emu_dim3(block), (shmem), __VA_ARGS__);                \
+    (ms) = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0_).count(); \
+  } while (0)
+
+#include "../../qpalm_amd/csrc/qpalm_capi.inc"

@@ -1,0 +1,427 @@
+"""Parity of the gfx950 path with the CPU oracle, through the C ABI (include/qpalm_gfx950.h).
+
+Every test runs twice: `[emu]` executes the kernel SOURCE on the host (fiber emulation, CPU-only
+test harness) and `[hip]` (marked gpu) executes the shipped HIP library on a real MI355X.
+
+Tolerances (fp64): element-wise arithmetic is reproduced operation by operation, so differences
+come only from reduction order / FMA inside SpMV, dot products and the LDL^T kernels:
+  * final x, y and per-iteration iterates: <= 1e-9 relative (north-star: iterates to a stated fp64
+    tolerance),  * final residual norms within 1e-8 of the oracle's,
+  * active sets, entering/leaving lists, iteration counts and statuses: exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from qpalm_amd.problems import fixture_qp, random_mpc_qp, random_qp
+from qpalm_amd.solver import Qpalm, QpalmBatch
+from tests.helpers import STATUS
+
+RTOL = 1e-9
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1.0, np.max(np.abs(b)))
+
+
+def oracle_for(p, st):
+    o = ob.OracleQP(*p.args(), c=p.c, settings=ob.default_settings(**st))
+    return o
+
+
+def sizes(ctx, small, big):
+    return small if ctx.kind == "emu" else big
+
+
+# ---------------------------------------------------------------- the reference's own suites
+def gsettings(ctx, golden, name, **over):
+    st = dict(golden["expect"][name].get("settings", {}))
+    st.update(over)
+    st["verbose"] = 0
+    return st
+
+
+@pytest.mark.parametrize("name,over", [
+    ("basic_qp", dict()), ("basic_qp", dict(scaling=0)), ("basic_qp", dict(proximal=0, scaling=2)),
+    ("basic_qp", dict(proximal=0, scaling=0)), ("basic_qp", dict(sigma_max=1e3)),
+    ("medium_qp", dict()), ("degen_hess", dict()), ("ls_qp", dict()),
+])
+def test_reference_solutions(ctx, golden, name, over):
+    e = golden["expect"][name]
+    st = gsettings(ctx, golden, name, **over)
+    p = fixture_qp(golden["problems"][name])
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    bt.solve()
+    info = bt.info(0)
+    assert int(info.status_val) == STATUS["SOLVED"]
+    x = bt.solution()[0][0]
+    if "rel_tol" in e:
+        for a, b in zip(x, e["solution"]):
+            assert abs(a - b) <= abs(e["rel_tol"] * b)
+    else:
+        assert np.max(np.abs(x - e["solution"])) <= e["abs_tol"]
+    o = oracle_for(p, st)
+    o.solve()
+    assert int(info.iter) == int(o.info.iter) and int(info.iter_out) == int(o.info.iter_out)
+    assert rel(x, o.x) <= RTOL and rel(bt.solution()[1][0], o.y) <= RTOL
+    assert abs(info.pri_res_norm - o.info.pri_res_norm) <= 1e-8 and abs(info.dua_res_norm - o.info.dua_res_norm) <= 1e-8
+    assert abs(info.objective - o.info.objective) <= 1e-9 * max(1.0, abs(o.info.objective))
+
+
+@pytest.mark.parametrize("name,status", [("prim_inf_qp", "PRIMAL_INFEASIBLE"), ("dua_inf_qp", "DUAL_INFEASIBLE")])
+@pytest.mark.parametrize("k", range(4))
+def test_reference_infeasible(ctx, golden, name, status, k):
+    st = gsettings(ctx, golden, name, **golden["expect"][name]["variants"][k])
+    bt = QpalmBatch(ctx, [fixture_qp(golden["problems"][name])], ctx.default_settings(**st))
+    bt.solve()
+    assert int(bt.info(0).status_val) == STATUS[status]
+
+
+def test_reference_status_paths(ctx, golden):
+    p = fixture_qp(golden["problems"]["basic_qp"])
+    base = gsettings(ctx, golden, "basic_qp")
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**dict(base, max_iter=1)))       # test_basic_qp_maxiter
+    bt.solve()
+    assert int(bt.info(0).status_val) == STATUS["MAX_ITER_REACHED"]
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**dict(base, eps_abs=1e-8, eps_rel=1e-8, inner_max_iter=2, max_iter=10)))
+    bt.solve()                                                                       # test_basic_qp_inner_maxiter
+    assert int(bt.info(0).status_val) == STATUS["MAX_ITER_REACHED"]
+    assert int(bt.info(0).iter) == 10
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**dict(base, time_limit=0.01 * 1e-3)))  # test_basic_qp_time_limit
+    bt.solve()
+    assert int(bt.info(0).status_val) == STATUS["TIME_LIMIT_REACHED"]
+
+
+@pytest.mark.parametrize("over,ykey", [(dict(scaling=2, proximal=1), "warm_y_scaled"), (dict(scaling=0, proximal=1), "warm_y"),
+                                       (dict(scaling=2, proximal=0), "warm_y"), (dict(scaling=0, proximal=0), "warm_y")])
+def test_reference_warm_start(ctx, golden, over, ykey):
+    e = golden["expect"]["basic_qp"]
+    st = gsettings(ctx, golden, "basic_qp", warm_start=1, **over)
+    p = fixture_qp(golden["problems"]["basic_qp"])
+    q = Qpalm(ctx)
+    q.settings = ctx.default_settings(**st)
+    q.set_problem(p)
+    q.setup()
+    q.warm_start(e["warm_x"], e[ykey])
+    q.solve()
+    assert int(q.info.iter) < e["warm_iter_lt"] and q.status_val == STATUS["SOLVED"]
+    for a, b in zip(q.x, e["solution"]):
+        assert abs(a - b) <= abs(1e-5 * b)
+    o = oracle_for(p, st)
+    o.warm_start(e["warm_x"], e[ykey])
+    o.solve()
+    assert int(q.info.iter) == int(o.info.iter)
+    assert rel(q.x, o.x) <= RTOL and rel(q.y, o.y) <= RTOL
+
+
+def test_reference_resolve_is_reproducible(ctx, golden):
+    # test_basic_qp_warm_start_resolve (test_basic_qp.c:275-307): same iterates to 1e-15, same iter
+    st = gsettings(ctx, golden, "basic_qp")
+    q = Qpalm(ctx)
+    q.settings = ctx.default_settings(**st)
+    q.set_problem(fixture_qp(golden["problems"]["basic_qp"]))
+    q.setup()
+    x0, y0 = q.batch.vec("x"), q.batch.vec("y")
+    q.solve()
+    xs, ys, it = q.x.copy(), q.y.copy(), int(q.info.iter)
+    q.warm_start(x0, y0)
+    q.solve()
+    assert int(q.info.iter) == it
+    assert np.max(np.abs(q.x - xs)) <= 1e-15 and np.max(np.abs(q.y - ys)) <= 1e-15
+
+
+def test_reference_update_suite(ctx, golden):
+    # suite_update: three tests on ONE workspace, in order (test_update.c:91-148)
+    e, pr = golden["expect"]["update"], golden["problems"]["update"]
+    st = gsettings(ctx, golden, "update")
+    p = fixture_qp(pr)
+    q = Qpalm(ctx)
+    q.settings = ctx.default_settings(**st)
+    q.set_problem(p)
+    q.setup()
+    o = oracle_for(p, st)
+    q.solve(); o.solve()
+    assert q.status_val == STATUS["SOLVED"] and np.max(np.abs(q.x - e["first"])) <= 1e-5
+    assert rel(q.x, o.x) <= RTOL
+    s = ctx.default_settings(**st)
+    so = ob.default_settings(**st)
+    for t in (s, so):
+        t.gamma_init *= 0.1; t.theta = 0.9; t.proximal = 1; t.scaling = 10
+    assert q.update_settings(s) == 0
+    o.update_settings(so)
+    q.solve(); o.solve()
+    assert q.status_val == STATUS["SOLVED"] and np.max(np.abs(q.x - e["first"])) <= 1e-5
+    assert int(q.info.iter) == int(o.info.iter) and rel(q.x, o.x) <= RTOL
+    bmin, bmax = np.array(pr["bmin"]), np.array(pr["bmax"])
+    bmin[0], bmax[1] = e["new_bmin0"], e["new_bmax1"]
+    assert q.update_bounds(bmin, bmax) == 0
+    o.update_bounds(bmin, bmax)
+    q.solve(); o.solve()
+    assert q.status_val == STATUS["SOLVED"] and np.max(np.abs(q.x - e["after_bounds"])) <= 1e-5
+    assert int(q.info.iter) == int(o.info.iter) and rel(q.x, o.x) <= RTOL
+    q.update_bounds(pr["bmin"], pr["bmax"]); o.update_bounds(pr["bmin"], pr["bmax"])
+    q.update_q(e["new_q"]); o.update_q(e["new_q"])
+    q.solve(); o.solve()
+    assert q.status_val == STATUS["SOLVED"] and np.max(np.abs(q.x - e["after_q"])) <= 1e-5
+    assert int(q.info.iter) == int(o.info.iter) and rel(q.x, o.x) <= RTOL
+
+
+def test_reference_error_handling(ctx, golden):
+    from qpalm_amd.capi import QpgError
+    pr = golden["problems"]["error_handling"]
+    p = fixture_qp(pr)
+    with pytest.raises(QpgError):   # test_invalid_settings_during_setup
+        QpalmBatch(ctx, [p], ctx.default_settings(max_iter=-1))
+    bad = fixture_qp(pr)
+    bad.bmin[0], bad.bmax[0] = 5.0, 0.0
+    with pytest.raises(QpgError):   # test_invalid_data_during_setup
+        QpalmBatch(ctx, [bad], ctx.default_settings(verbose=0))
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(verbose=0))
+    assert int(bt.info(0).status_val) == STATUS["UNSOLVED"]
+    assert bt.update_settings(ctx.default_settings(max_iter=-10)) != 0
+    assert int(bt.info(0).status_val) == STATUS["ERROR"]
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(verbose=0))
+    assert bt.update_settings(ctx.default_settings(verbose=0, scaling=0)) != 0   # decreasing scaling
+    assert int(bt.info(0).status_val) == STATUS["ERROR"]
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(verbose=0))
+    assert bt.update_bounds(bad.bmin[None, :], bad.bmax[None, :]) != 0
+    assert int(bt.info(0).status_val) == STATUS["ERROR"]
+
+
+# ---------------------------------------------------------------- the boundary (solver_interface.h)
+def test_boundary_golden_vectors(ctx, golden):
+    e, pr = golden["expect"]["solver_interface"], golden["problems"]["solver_interface"]
+    p = fixture_qp(pr)
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(verbose=0, eps_abs=1e-6, eps_rel=1e-6, scaling=0))
+    tol = e["tol"]
+    assert np.max(np.abs(bt.mat_vec("A", e["x"]) - e["A_x"])) <= tol
+    assert np.max(np.abs(bt.mat_vec("Q", e["x"]) - e["Q_x"])) <= tol
+    assert np.max(np.abs(bt.mat_tpose_vec("Q", e["x"]) - e["Q_x"])) <= tol
+    assert np.max(np.abs(bt.mat_tpose_vec("A", e["Ad_in"]) - e["At_Ad"])) <= tol
+    # test_ldlchol (test_solver_interface.c:144-160)
+    bt.set_scalar("proximal", 0)
+    bt.set_vec("dphi", [-v for v in e["ldl_rhs"]])
+    bt.op("ldlchol"); bt.op("ldlsolveLD_neg_dphi")
+    assert np.max(np.abs(bt.vec("d") - e["ldl_d"])) <= tol
+    bt.set_scalar("proximal", 1)
+    bt.set_scalar("gamma", e["ldl_gamma"])
+    bt.op("ldlchol"); bt.op("ldlsolveLD_neg_dphi")
+    assert np.max(np.abs(bt.vec("d") - e["ldl_d_prox"])) <= tol
+
+
+def _prep_pair(ctx, n, m, seed, **kw):
+    p = random_qp(n, m, seed=seed, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n))
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    st.update(kw)
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    o = oracle_for(p, st)
+    return p, st, bt, o
+
+
+def test_boundary_factor_update_solve_linesearch(ctx):
+    """ldlcholQAtsigmaA, ldlupdate/ldldowndate, ldlsolveLD_neg_dphi and exact_linesearch on a state
+    taken from the middle of an oracle solve: the factor itself is compared, entry by entry."""
+    n, m = sizes(ctx, (70, 140), (300, 600))
+    p, st, bt, o = _prep_pair(ctx, n, m, 1234)
+    # run both for a few iterations so that sigma / iterates are non-trivial
+    o.enable_trace(64)
+    so = ob.default_settings(**dict(st, max_iter=6))
+    o2 = ob.OracleQP(*p.args(), settings=so)
+    o2.solve()
+    bt.iterate(6)
+    for v in ("x", "y", "Ax", "Qx"):
+        assert rel(bt.vec(v), o2.vec(v)) <= RTOL
+    L = ob.lib()
+    # a synthetic active set: every third constraint
+    act = (np.arange(m) % 3 == 0).astype(np.int64)
+    o2.ivec("active")  # touch
+    import ctypes as C
+    ln = ob.c_int(0)
+    pa = L.oq_get_ivec(o2.w, b"active", C.byref(ln))
+    np.ctypeslib.as_array(pa, shape=(m,))[:] = act
+    bt.set_ivec("active", act)
+    L.oq_ldlcholQAtsigmaA(o2.w)
+    bt.op("ldlcholQAtsigmaA")
+    Lo, Do = o2.factor()
+    Lg, Dg = bt.factor()
+    assert rel(Dg, Do) <= 1e-11 and np.max(np.abs(np.tril(Lg, -1) - np.tril(Lo, -1))) <= 1e-10
+    # rank update with entering = some inactive rows, downdate with leaving = some active rows
+    enter = np.where(act == 0)[0][:21]
+    leave = np.where(act == 1)[0][5:17]
+    for name, lst in (("enter", enter), ("leave", leave)):
+        bt.set_ivec(name, lst)
+        pe = L.oq_get_ivec(o2.w, name.encode(), C.byref(ln))
+        # oracle lists live in m-sized buffers
+        np.ctypeslib.as_array(pe, shape=(m,))[:len(lst)] = lst
+    # oracle counters nb_enter/nb_leave are set through the same lists' lengths
+    # (oq_set_scalar has no entry for them; emulate set_entering_leaving by writing active_old)
+    act_new = act.copy(); act_new[enter] = 1; act_new[leave] = 0
+    pao = L.oq_get_ivec(o2.w, b"active_old", C.byref(ln))
+    np.ctypeslib.as_array(pao, shape=(m,))[:] = act
+    np.ctypeslib.as_array(pa, shape=(m,))[:] = act_new
+    L.oq_set_entering_leaving_constraints(o2.w)
+    assert np.array_equal(o2.ivec("enter"), enter) and np.array_equal(o2.ivec("leave"), leave)
+    L.oq_ldlupdate_entering_constraints(o2.w)
+    L.oq_ldldowndate_leaving_constraints(o2.w)
+    bt.set_scalar("nb_enter", len(enter)); bt.set_scalar("nb_leave", len(leave))
+    bt.op("ldlupdate_entering_constraints")
+    bt.op("ldldowndate_leaving_constraints")
+    Lo, Do = o2.factor()
+    Lg, Dg = bt.factor()
+    assert rel(Dg, Do) <= 1e-10 and np.max(np.abs(np.tril(Lg, -1) - np.tril(Lo, -1))) <= 1e-9
+    # the updated factor must equal a fresh factorisation of the new active set (property)
+    bt.set_ivec("active", act_new)
+    np.ctypeslib.as_array(pa, shape=(m,))[:] = act_new
+    L.oq_ldlcholQAtsigmaA(o2.w)
+    Lf, Df = o2.factor()
+    assert rel(Dg, Df) <= 1e-8
+    # solve with the factor
+    rhs = np.random.default_rng(5).standard_normal(n)
+    o2.vec("dphi", copy=False)[:] = rhs
+    bt.set_vec("dphi", rhs)
+    bt.op("ldlcholQAtsigmaA")
+    L.oq_ldlsolveLD_neg_dphi(o2.w)
+    bt.op("ldlsolveLD_neg_dphi")
+    assert rel(bt.vec("d"), o2.vec("d")) <= 1e-9
+    # line search on that direction
+    tau_o = L.oq_exact_linesearch(o2.w)
+    tau_g = bt.exact_linesearch()
+    assert abs(tau_g - tau_o) <= 1e-9 * max(1.0, abs(tau_o))
+    assert rel(bt.vec("Qd"), o2.vec("Qd")) <= 1e-12 and rel(bt.vec("Ad"), o2.vec("Ad")) <= 1e-12
+    assert np.array_equal(bt.vec("delta"), o2.vec("delta")) or rel(bt.vec("delta"), o2.vec("delta")) <= 1e-12
+
+
+def test_boundary_residuals_and_active_sets_bit_exact(ctx):
+    n, m = sizes(ctx, (50, 100), (400, 800))
+    p, st, bt, o = _prep_pair(ctx, n, m, 77)
+    so = ob.default_settings(**dict(st, max_iter=4))
+    o2 = ob.OracleQP(*p.args(), settings=so)
+    o2.solve()
+    bt.iterate(4)
+    L = ob.lib()
+    # copy the oracle's state bit for bit, then compare one compute_residuals + active-set pass
+    for v in ("x", "y", "Ax", "Qx", "x0", "sigma", "sigma_inv"):
+        bt.set_vec(v, o2.vec(v))
+    bt.set_scalar("gamma", o2.scalar("gamma"))
+    L.oq_compute_residuals(o2.w)
+    bt.op("compute_residuals")
+    for v in ("Axys", "z", "pri_res", "yh"):     # pure element-wise: bit exact
+        assert np.array_equal(bt.vec(v), o2.vec(v)), v
+    assert rel(bt.vec("Atyh"), o2.vec("Atyh")) <= 1e-13 and rel(bt.vec("dphi"), o2.vec("dphi")) <= 1e-13
+    L.oq_set_active_constraints(o2.w)
+    L.oq_set_entering_leaving_constraints(o2.w)
+    bt.set_ivec("active_old", o2.ivec("active_old"))
+    bt.op("set_active_constraints")
+    assert np.array_equal(bt.ivec("active"), o2.ivec("active"))
+    ne, nl = int(bt.stats(0).nb_enter), int(bt.stats(0).nb_leave)
+    assert np.array_equal(bt.ivec("enter", length=ne), o2.ivec("enter"))
+    assert np.array_equal(bt.ivec("leave", length=nl), o2.ivec("leave"))
+
+
+# ---------------------------------------------------------------- whole solves vs the oracle
+def _compare_solve(ctx, probs, st, rank_thr=-1):
+    ctx.set_option("update_rank_threshold", rank_thr)
+    bt = QpalmBatch(ctx, probs, ctx.default_settings(**st))
+    bt.solve()
+    xs, ys = bt.solution()
+    for k, p in enumerate(probs):
+        o = oracle_for(p, st)
+        o.solve()
+        info = bt.info(k)
+        assert int(info.status_val) == o.status_val
+        assert int(info.iter) == int(o.info.iter) and int(info.iter_out) == int(o.info.iter_out), (k, info.iter, o.info.iter)
+        assert rel(xs[k], o.x) <= RTOL and rel(ys[k], o.y) <= RTOL
+        assert abs(info.pri_res_norm - o.info.pri_res_norm) <= 1e-8
+        assert abs(info.dua_res_norm - o.info.dua_res_norm) <= 1e-8
+        if rank_thr < 0:
+            s = bt.stats(k)
+            assert int(s.n_refactor) == o.counter("n_refactor") and int(s.n_rank1) == o.counter("n_rank1")
+        assert np.array_equal(bt.ivec("active", k), o.ivec("active"))
+    ctx.set_option("update_rank_threshold", -1)
+    return bt
+
+
+def test_random_qps_match_oracle(ctx):
+    n, m = sizes(ctx, (40, 80), (200, 400))
+    nb = sizes(ctx, 3, 8)
+    probs = [random_qp(n, m, seed=1000 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(nb)]
+    _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0))
+
+
+def test_random_qps_unscaled_noprox(ctx):
+    n, m = sizes(ctx, (30, 60), (150, 300))
+    probs = [random_qp(n, m, seed=2000 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(2)]
+    _compare_solve(ctx, probs, dict(eps_abs=1e-7, eps_rel=1e-7, verbose=0, scaling=0))
+    _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, proximal=0, scaling=3))
+
+
+def test_refactor_policy_changes_speed_not_results(ctx):
+    """The own refactor-vs-update threshold (a speed policy) must not change iterates."""
+    n, m = sizes(ctx, (40, 80), (200, 400))
+    probs = [random_qp(n, m, seed=3000, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n))]
+    _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0), rank_thr=2)
+
+
+def test_mpc_qps_match_oracle(ctx):
+    T = sizes(ctx, 3, 10)
+    probs = [random_mpc_qp(T=T, nx=sizes(ctx, 4, 10), nu=sizes(ctx, 2, 5), seed=k) for k in range(2)]
+    _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0))
+
+
+def test_per_iteration_trace(ctx):
+    """Per-iteration iterates, step sizes and active sets against the oracle's trace."""
+    n, m = sizes(ctx, (40, 80), (250, 500))
+    p, st, bt, o = _prep_pair(ctx, n, m, 4242)
+    o.enable_trace(400)
+    o.solve()
+    tr = o.trace()
+    K = len(tr["kind"])
+    assert K >= 8
+    for k in range(K):
+        bt.iterate(1)
+        s = bt.stats(0)
+        assert int(s.last_kind) == int(tr["kind"][k]), k
+        assert rel(bt.vec("x"), tr["x"][k]) <= RTOL and rel(bt.vec("y"), tr["y"][k]) <= RTOL, k
+        if tr["kind"][k] == 0:
+            assert abs(s.tau - tr["tau"][k]) <= 1e-9 * max(1.0, abs(tr["tau"][k])), k
+            assert int(s.last_fact) == int(tr["fact"][k]), k
+            assert np.array_equal(bt.ivec("active"), tr["active"][k]), k
+            assert (int(s.nb_active), int(s.nb_enter), int(s.nb_leave)) == (int(tr["nb_active"][k]), int(tr["nb_enter"][k]), int(tr["nb_leave"][k]))
+            assert rel(bt.vec("d"), tr["d"][k]) <= 1e-8, k
+        assert abs(s.gamma - tr["gamma"][k]) <= 1e-12 * abs(tr["gamma"][k]), k
+    bt.iterate(1)
+    assert bt.num_unfinished() == 0 and int(bt.info(0).status_val) == o.status_val and int(bt.info(0).iter) == int(o.info.iter)
+
+
+def test_work_queue_more_qps_than_slots(ctx):
+    """B > max_slots: workgroups pull QPs from the atomic queue and reuse their factor slot."""
+    ctx.set_option("max_slots", 2)
+    n, m = sizes(ctx, (24, 48), (100, 200))
+    probs = [random_qp(n, m, seed=500 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(5)]
+    try:
+        _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0))
+    finally:
+        ctx.set_option("max_slots", 512)
+
+
+def test_warm_started_mpc_sequence(ctx):
+    """update_bounds + warm_start between solves (the MPC use of the reference,
+    simulations/randomMPCsequential.m:158-177)."""
+    T, nx, nu = sizes(ctx, (3, 4, 2), (10, 10, 5))
+    p = random_mpc_qp(T=T, nx=nx, nu=nu, seed=3)
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    q = Qpalm(ctx); q.settings = ctx.default_settings(**st); q.set_problem(p); q.setup()
+    o = oracle_for(p, st)
+    q.solve(); o.solve()
+    rng = np.random.default_rng(0)
+    for step in range(2):
+        bmin, bmax = p.bmin.copy(), p.bmax.copy()
+        x0 = 0.5 * rng.standard_normal(nx)
+        bmin[:nx] = x0; bmax[:nx] = x0
+        assert q.update_bounds(bmin, bmax) == 0
+        o.update_bounds(bmin, bmax)
+        xw, yw = q.x.copy(), q.y.copy()
+        q.warm_start(xw, yw); o.warm_start(xw, yw)
+        q.solve(); o.solve()
+        assert q.status_val == o.status_val and int(q.info.iter) == int(o.info.iter)
+        assert rel(q.x, o.x) <= RTOL and rel(q.y, o.y) <= RTOL
