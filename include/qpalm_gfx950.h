@@ -134,6 +134,7 @@ int  qpg_batch_setup(qpg_batch *bt);                               /* upload + R
 int  qpg_batch_warm_start(qpg_batch *bt, const qpg_float *x, const qpg_float *y); /* [B][n], [B][m] or NULL */
 int  qpg_batch_solve(qpg_batch *bt);                               /* run every QP to termination */
 int  qpg_batch_iterate(qpg_batch *bt, qpg_int k);                  /* at most k more loop iterations each */
+int  qpg_batch_last_solve_ms(qpg_batch *bt, float *ms);            /* HIP-event time of the last solve/iterate launch */
 int  qpg_batch_num_unfinished(qpg_batch *bt, qpg_int *count);
 int  qpg_batch_update_settings(qpg_batch *bt, const QPGSettings *s);
 int  qpg_batch_update_bounds(qpg_batch *bt, const qpg_float *bmin, const qpg_float *bmax); /* [B][m] or NULL */

@@ -91,6 +91,11 @@ class QpalmBatch:
     def iterate(self, k=1):
         self._check(self.L.qpg_batch_iterate(self.h, int(k)))
 
+    def last_solve_ms(self):
+        ms = C.c_float(0.0)
+        self._check(self.L.qpg_batch_last_solve_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
     def num_unfinished(self):
         c = capi.c_int(0)
         self._check(self.L.qpg_batch_num_unfinished(self.h, C.byref(c)))
