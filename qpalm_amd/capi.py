@@ -47,7 +47,8 @@ class Stats(C.Structure):
     _fields_ = [(k, c_int) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve", "n_sigma_updates",
                                      "n_boost_gamma", "nb_active", "nb_enter", "nb_leave", "last_kind", "last_fact")] + \
                [(k, c_float) for k in ("gamma", "tau", "eta", "beta", "eps_pri", "eps_dua", "eps_dua_in", "sc_c",
-                                       "ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")]
+                                       "ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")] + \
+               [("ms_dbg", c_float * 8)]
 
 
 class QpgError(RuntimeError):

@@ -18,7 +18,10 @@
 
 #ifdef QPALM_EMU
 #define QP_WAVE_SYNC() emu_wave_sync()
+#define QP_SCHED_BARRIER() do { } while (0)
 #else
+/* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
+#define QP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define QP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
@@ -107,85 +110,133 @@ QPN double form_schur(const qpg_view &V, int b, double *Lslot, bool with_AtSA, b
 
 /* ---------------------------------------------------------------------------------------------
  * dense_factor: in-place LDL^T of the lower triangle held in the slot (no pivoting, negative
- * pivots accepted like CHOLMOD's simplicial LDL^T).  Left-looking over block columns of NB:
- * thread t owns rows t, t+QP_T, ... (RPT of them) and keeps its NB-wide panel row in registers;
- * the (D L')-tile of the block rows is staged through LDS and broadcast.
+ * pivots accepted like CHOLMOD's simplicial LDL^T).  Left-looking over block columns of 32.
+ *
+ *  (1) panel update  P = H(J:n, Jb) - L(J:n, 0:J) D L(Jb, 0:J)'  on the matrix cores
+ *      (v_mfma_f64_16x16x4_f64): wavefront w owns the 16-row tiles w, w+NW, ... and both 16-column
+ *      tiles of the block; operands are read straight from the column-major panel (lane l reads
+ *      element [k + (l>>4)][base + (l&15)], i.e. four 128-byte column segments per fragment), the
+ *      panel-column fragment is the A operand so that accumulator registers run down rows and the
+ *      write-back is coalesced.
+ *  (2) the 32 x 32 diagonal block is factorised by wavefront 0 (lane = row, registers + shuffles);
+ *  (3) rows below the block are finished one row per thread with the block's L, D from LDS.
  * ------------------------------------------------------------------------------------------- */
-#define QP_FNB 16
-#define QP_FKC 32
+#define QP_FNB 32
 struct FactorLds {
-  double Bt[QP_FKC][QP_FNB];
   double Ld[QP_FNB][QP_FNB + 1];
   double dv[QP_FNB];
+  double colbuf[QP_FNB];
 };
 
+/* Panel update of block column J for a wavefront that owns NTJ consecutive-strided 16-row tiles
+ * (tile index J/16 + wid + NW*t): branch-free k loop, fragments of step k+4 are in flight while the
+ * 2*NTJ MFMAs of step k execute. */
+template <int NTJ>
+QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tile0 = J / 16 + wid;
+  qp_double4 acc[NTJ][2];
+  int rowc[NTJ];
+#pragma unroll
+  for (int t = 0; t < NTJ; t++) {
+    const int row = (tile0 + t * QP_NW) * 16 + l15;
+    rowc[t] = (row < n) ? row : (n - 1);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int col = J + ct * 16 + l4 + 4 * r;
+        acc[t][ct][r] = (row < n && col < n && row >= col) ? L[(size_t)col * ld + row] : 0.0;
+      }
+  }
+  const int rowp0 = (J + l15 < n) ? (J + l15) : (n - 1), rowp1 = (J + 16 + l15 < n) ? (J + 16 + l15) : (n - 1);
+  if (J > 0) {
+    double pa0, pa1, bv[NTJ];
+    {
+      const double *colk = L + (size_t)l4 * ld;
+      const double dk = Dg[l4];
+      pa0 = -(colk[rowp0] * dk); pa1 = -(colk[rowp1] * dk);
+#pragma unroll
+      for (int t = 0; t < NTJ; t++) bv[t] = colk[rowc[t]];
+    }
+#pragma unroll 1
+    for (int k = 0; k < J; k += 4) {
+      const int kn = (k + 4 < J) ? (k + 4) : k; /* last step re-reads its own fragments */
+      const double *colk = L + (size_t)(kn + l4) * ld;
+      const double dk = Dg[kn + l4];
+      const double na0 = colk[rowp0], na1 = colk[rowp1];
+      double nb[NTJ];
+#pragma unroll
+      for (int t = 0; t < NTJ; t++) nb[t] = colk[rowc[t]];
+#pragma unroll
+      for (int t = 0; t < NTJ; t++) {
+        acc[t][0] = QP_MFMA_F64(pa0, bv[t], acc[t][0]);
+        acc[t][1] = QP_MFMA_F64(pa1, bv[t], acc[t][1]);
+      }
+      pa0 = -(na0 * dk); pa1 = -(na1 * dk);
+#pragma unroll
+      for (int t = 0; t < NTJ; t++) bv[t] = nb[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTJ; t++) {
+    const int row = (tile0 + t * QP_NW) * 16 + l15;
+    if (row < n) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int col = J + ct * 16 + l4 + 4 * r;
+          if (col < n && row >= col) L[(size_t)col * ld + row] = acc[t][ct][r];
+        }
+    }
+  }
+}
+
 template <int RPT>
-QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds) {
+QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *tdbg) {
   FactorLds &F = *(FactorLds *)lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_FNB;
+  constexpr int NT = (RPT * QP_T / 16 + QP_NW - 1) / QP_NW; /* 16-row tiles per wavefront, at most */
   __syncthreads();
+  long long tq0 = QP_CLOCK();
   for (int J = 0; J < n; J += NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
-    double acc[RPT][QP_FNB];
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int i = tid + r * QP_T;
-#pragma unroll
-      for (int c = 0; c < NB; c++) acc[r][c] = (i < n && c < jb && i >= J + c) ? L[(size_t)(J + c) * ld + i] : 0.0;
-    }
-    for (int k0 = 0; k0 < J; k0 += QP_FKC) {
-      const int kc = (J - k0 < QP_FKC) ? (J - k0) : QP_FKC;
-      __syncthreads();
-      for (int e = tid; e < QP_FKC * NB; e += QP_T) {
-        const int kk = e / NB, c = e % NB;
-        F.Bt[kk][c] = (kk < kc && c < jb) ? L[(size_t)(k0 + kk) * ld + (J + c)] * Dg[k0 + kk] : 0.0;
-      }
-      __syncthreads();
-      for (int kk = 0; kk < kc; kk++) {
-        double a[RPT];
-#pragma unroll
-        for (int r = 0; r < RPT; r++) {
-          const int i = tid + r * QP_T;
-          a[r] = (i >= J && i < n) ? L[(size_t)(k0 + kk) * ld + i] : 0.0;
-        }
-#pragma unroll
-        for (int c = 0; c < NB; c++) {
-          const double bv = F.Bt[kk][c];
-#pragma unroll
-          for (int r = 0; r < RPT; r++) acc[r][c] = QP_FMA(-a[r], bv, acc[r][c]);
-        }
-      }
+    /* ---- (1) panel update on the matrix cores ------------------------------------------------ */
+    {
+      const int ntiles = (n - J + 15) / 16;
+      const int ntj = (ntiles + QP_NW - 1) / QP_NW; /* same for every wavefront */
+      if (ntj <= 1) factor_panel_update<1>(L, Dg, n, ld, J);
+      else if (ntj == 2) factor_panel_update<(NT >= 2 ? 2 : 1)>(L, Dg, n, ld, J);
+      else if (ntj == 3) factor_panel_update<(NT >= 3 ? 3 : 1)>(L, Dg, n, ld, J);
+      else if (ntj == 4) factor_panel_update<(NT >= 4 ? 4 : 1)>(L, Dg, n, ld, J);
+      else if (ntj <= 6) factor_panel_update<(NT >= 6 ? 6 : 1)>(L, Dg, n, ld, J);
+      else if (ntj <= 8) factor_panel_update<(NT >= 8 ? 8 : 1)>(L, Dg, n, ld, J);
+      else if (ntj <= 12) factor_panel_update<(NT >= 12 ? 12 : 1)>(L, Dg, n, ld, J);
+      else factor_panel_update<(NT >= 16 ? 16 : 1)>(L, Dg, n, ld, J);
     }
     __syncthreads();
-    /* rows of the diagonal block -> LDS */
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int i = tid + r * QP_T;
-      if (i >= J && i < J + jb) {
-#pragma unroll
-        for (int c = 0; c < NB; c++) F.Ld[i - J][c] = acc[r][c];
-      }
-    }
-    __syncthreads();
-    if (wid == 0) { /* unblocked LDL^T of the jb x jb block; lane = row, row kept in registers */
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[4] += tq1 - tq0; tq0 = tq1; }
+    /* ---- (2) diagonal block: right-looking, lane = row (registers), columns exchanged via LDS - */
+    if (wid == 0) {
       double p[QP_FNB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) p[c] = (lane < jb && c <= lane) ? F.Ld[lane][c] : 0.0;
+      for (int c = 0; c < NB; c++) p[c] = (lane < jb && c <= lane) ? L[(size_t)(J + c) * ld + (J + lane)] : 0.0;
 #pragma unroll
       for (int c = 0; c < NB; c++) {
         if (c < jb) {
-          const double dc = __shfl(p[c], c);
+          if (lane < NB) F.colbuf[lane] = p[c]; /* un-normalised column c */
+          QP_WAVE_SYNC();
+          const double dc = F.colbuf[c];
           const double lic = p[c] / dc;
 #pragma unroll
-          for (int c2 = c + 1; c2 < NB; c2++) {
-            const double u = __shfl(p[c], c2);
-            p[c2] = QP_FMA(-lic, u, p[c2]);
-          }
+          for (int c2 = c + 1; c2 < NB; c2++) p[c2] = QP_FMA(-lic, F.colbuf[c2], p[c2]);
           if (lane > c) p[c] = lic;
+          QP_WAVE_SYNC();
         }
       }
-      QP_WAVE_SYNC();
       if (lane < jb) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
@@ -195,25 +246,28 @@ QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds) {
       }
     }
     __syncthreads();
-    /* panel rows below the block */
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
+    /* ---- (3) rows below the block: l_ic = (p_ic - sum_{c1<c} u_ic1 l_c,c1) / d_c ---------------- */
+#pragma unroll 1
+    for (int i = J + jb + tid; i < n; i += QP_T) {
+      double u[QP_FNB];
 #pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int i = tid + r * QP_T;
-      if (i >= J + jb && i < n) {
+      for (int c = 0; c < NB; c++) u[c] = (c < jb) ? L[(size_t)(J + c) * ld + i] : 0.0;
 #pragma unroll
-        for (int c = 0; c < NB; c++) {
-          if (c < jb) {
-            double v = acc[r][c];
+      for (int c = 0; c < NB; c++) {
+        if (c < jb) {
+          double v = u[c];
 #pragma unroll
-            for (int c1 = 0; c1 < c; c1++) v = QP_FMA(-acc[r][c1], F.Ld[c][c1], v);
-            acc[r][c] = v; /* un-normalised l*d */
-          }
+          for (int c1 = 0; c1 < c; c1++) v = QP_FMA(-u[c1], F.Ld[c][c1], v);
+          u[c] = v; /* un-normalised l*d */
         }
-#pragma unroll
-        for (int c = 0; c < NB; c++)
-          if (c < jb) L[(size_t)(J + c) * ld + i] = acc[r][c] / F.dv[c];
       }
+#pragma unroll
+      for (int c = 0; c < NB; c++)
+        if (c < jb) L[(size_t)(J + c) * ld + i] = u[c] / F.dv[c];
     }
+    __syncthreads();
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
   }
   __syncthreads();
 }
@@ -254,7 +308,13 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
     __syncthreads();
     for (int i = J + jb + tid; i < n; i += QP_T) {
       double acc = xs[i];
-      for (int c = 0; c < jb; c++) acc = QP_FMA(-L[(size_t)(J + c) * ld + i], xs[J + c], acc);
+      for (int g = 0; g < jb; g += 8) { /* 8 independent column loads in flight per row */
+        double lv[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) lv[cc] = (g + cc < jb) ? L[(size_t)(J + g + cc) * ld + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) if (g + cc < jb) acc = QP_FMA(-lv[cc], xs[J + g + cc], acc);
+      }
       xs[i] = acc;
     }
   }
@@ -268,6 +328,7 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
     for (int c = wid; c < jb; c += QP_NW) {
       double s = 0.0;
       const double *col = L + (size_t)(J + c) * ld;
+#pragma unroll 4
       for (int i = J + jb + lane; i < n; i += 64) s = QP_FMA(col[i], xs[i], s);
       s = wave_sum(s);
       if (lane == 0) T.part[c] = s;
@@ -293,28 +354,49 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
 
 /* ---------------------------------------------------------------------------------------------
  * dense_updown: L D L' <- L D L' + sum_r s_r w_r w_r'   (s_r = +1 update, -1 downdate), the columns
- * w_r being columns cols[r] of At_sqrt_sigma.  Up to K ranks are applied per sweep over the panel.
+ * w_r being columns cols[r] of At_sqrt_sigma.  Up to K ranks are applied per sweep over the panel,
+ * so the panel is read and written once per K ranks (16 B per entry and sweep).
  *
- * Per column j and rank r (Davis & Hager C1, in the division-free-chain form):
+ * Per column j and rank r (Davis & Hager method C1), with alpha_r carried along the columns:
  *     p = s w_j^2/alpha ; d_new = d + p ; gamma = -s w_j/(alpha d_new) ; alpha <- alpha d_new/d
  *     for i > j:  w_i -= w_j l_ij ;  l_ij -= gamma w_i
  * Thread t owns rows t, t+QP_T, ... and keeps their K running w values in registers for the whole
- * sweep; per block column the (w_j, gamma) table of the block is produced by wavefront 0 from the
- * block's own rows and broadcast through LDS.
+ * sweep.  Per block column of 32: wavefront 0 runs the recurrence on the block's own rows (lane =
+ * row, everything in registers; rank-indexed scalars are produced with lane = rank, one reciprocal
+ * per column on the critical path, DPP row scans) and publishes the (w_j, gamma) table through LDS;
+ * then every thread applies the table to its rows below the block with L streamed from HBM.
  * ------------------------------------------------------------------------------------------- */
-#define QP_UNB 16
+#define QP_UNB 32
+template <int K>
 struct UpdownLds {
-  double Wd[QP_UNB][QPG_KMAX];
   double Ld[QP_UNB][QP_UNB + 1];
+  double Wd[QP_UNB][K + 1];
+  double cwg[QP_UNB][K][2]; /* (w_j, gamma) per column and rank, read as one 16-byte broadcast */
+  double Wt[K];
   double dd[QP_UNB];
-  double cw[QP_UNB][QPG_KMAX];
-  double cg[QP_UNB][QPG_KMAX];
 };
+
+#ifdef QPALM_EMU
+template <int N> QPD double qp_row_shr(double v) { /* DPP row_shr:N within rows of 16 lanes, zero fill */
+  const int lane = threadIdx.x & 63;
+  const bool ok = (lane & 15) >= N;
+  const double r = emu_exchange(v, ok ? lane - N : lane);
+  return ok ? r : 0.0;
+}
+#else
+template <int N> QPD double qp_row_shr(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+#endif
 
 template <int RPT, int K>
 QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *cols, int n_up,
-                      const int *cols_dn, int n_dn, QpShared &S, char *lds) {
-  UpdownLds &U = *(UpdownLds *)lds;
+                      const int *cols_dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
+  static_assert(K <= 16, "rank block must fit one DPP row");
+  UpdownLds<K> &U = *(UpdownLds<K> *)lds;
   const int n = V.n, ld = V.ld, NB = QP_UNB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
@@ -323,6 +405,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
   for (int r0 = 0; r0 < nr; r0 += K) {
     const int kk = (nr - r0 < K) ? (nr - r0) : K;
     __syncthreads();
+    long long tq0 = QP_CLOCK();
     for (int e = tid; e < kk * n; e += QP_T) Wst[e] = 0.0;
     __syncthreads();
     int jmin = n;
@@ -343,10 +426,11 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
 #pragma unroll
       for (int r = 0; r < K; r++) w[rr][r] = (i < n && r < kk) ? Wst[(size_t)r * n + i] : 0.0;
     }
-    double alpha = 1.0; /* lane r of wavefront 0 carries alpha_r */
+    double alpha = 1.0, ialpha = 1.0; /* lane r of wavefront 0 carries alpha_r and 1/alpha_r */
     const int grank = r0 + lane;
     const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
     const int J0 = (jmin / NB) * NB;
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1; }
     for (int J = J0; J < n; J += NB) {
       const int jb = (n - J < NB) ? (n - J) : NB;
 #pragma unroll
@@ -362,67 +446,140 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
         if (c > c1) U.Ld[c][c1] = L[(size_t)(J + c1) * ld + (J + c)];
       }
       if (tid < jb) U.dd[tid] = Dg[J + tid];
+      if (jb < NB) for (int e = tid; e < (NB - jb) * K; e += QP_T) { U.cwg[jb + e / K][e % K][0] = 0.0; U.cwg[jb + e / K][e % K][1] = 0.0; }
       __syncthreads();
       if (wid == 0) {
-        for (int c1 = 0; c1 < jb; c1++) {
-          /* A-step: lane = rank */
-          const double wv = (lane < kk) ? U.Wd[c1][lane] : 0.0;
-          const double p = (lane < kk) ? sg * wv * wv / alpha : 0.0;
-          double incl = p;
+        double wrow[K];
 #pragma unroll
-          for (int o = 1; o < K; o <<= 1) { const double u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-          double excl = __shfl_up(incl, 1);
-          if (lane == 0) excl = 0.0;
-          const double d0 = U.dd[c1];
-          const double dnew = d0 + incl, dprev = d0 + excl;
-          if (lane < kk) {
-            U.cw[c1][lane] = wv;
-            U.cg[c1][lane] = -sg * wv / (alpha * dnew);
-            alpha = alpha * dnew / dprev;
-          }
-          QP_WAVE_SYNC();
-          if (lane == kk - 1) U.dd[c1] = dnew;
-          /* B-step: lane = row of the diagonal block */
-          if (lane > c1 && lane < jb) {
-            double l = U.Ld[lane][c1];
+        for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[lane][r] : 0.0;
 #pragma unroll
-            for (int r = 0; r < K; r++) {
-              if (r < kk) {
-                double wr = U.Wd[lane][r];
-                wr = QP_FMA(-U.cw[c1][r], l, wr);
-                l = QP_FMA(-U.cg[c1][r], wr, l);
-                U.Wd[lane][r] = wr;
-              }
+        for (int c1 = 0; c1 < NB; c1++) {
+          if (c1 < jb) {
+            const double lcur = (lane > c1 && lane < jb) ? U.Ld[lane][c1] : 0.0; /* issued early, used after the scalars */
+            if (lane == c1) {
+#pragma unroll
+              for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
             }
-            U.Ld[lane][c1] = l;
+            QP_WAVE_SYNC();
+            /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
+            const double wv = (lane < kk) ? U.Wt[lane] : 0.0;
+            const double d0 = U.dd[c1];
+            const double p = sg * wv * wv * ialpha;
+            double incl = p;
+            if (K > 1) incl += qp_row_shr<1>(incl);
+            if (K > 2) incl += qp_row_shr<2>(incl);
+            if (K > 4) incl += qp_row_shr<4>(incl);
+            if (K > 8) incl += qp_row_shr<8>(incl);
+            const double excl = qp_row_shr<1>(incl);
+            const double dnew = d0 + incl, dprev = d0 + excl;
+            const double rdn = 1.0 / dnew, rdp = 1.0 / dprev;
+            const double gam = -sg * wv * ialpha * rdn;
+            if (lane < K) { U.cwg[c1][lane][0] = -wv; U.cwg[c1][lane][1] = -gam; } /* stored negated: plain FMAs below */
+            alpha = alpha * dnew * rdp;
+            ialpha = ialpha * dprev * rdn;
+            if (lane == kk - 1) U.dd[c1] = dnew;
+            QP_WAVE_SYNC();
+            /* rows of the block: lane = row; all K coefficient pairs are fetched first, then the
+             * l chain is one FMA per rank: l <- (1 + g w_j) l - g w_r ; w_r <- w_r - w_j l_r */
+            {
+              double l = lcur;
+#pragma unroll
+              for (int rb = 0; rb < K; rb += 8) {
+                double cw[8], cg[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[c1][rb + r][1] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                  if (rb + r < K) {
+                    const double ca = QP_FMA(cg[r], cw[r], 1.0);       /* 1 + gamma w_j */
+                    const double t = cg[r] * wrow[rb + r];             /* -gamma w_r */
+                    const double wn = QP_FMA(cw[r], l, wrow[rb + r]);  /* w_r - w_j l */
+                    l = QP_FMA(ca, l, t);
+                    if (lane > c1) wrow[rb + r] = wn;
+                  }
+                }
+                QP_SCHED_BARRIER();
+              }
+              if (lane > c1 && lane < jb) U.Ld[lane][c1] = l;
+            }
+            QP_SCHED_BARRIER();
           }
-          QP_WAVE_SYNC();
         }
       }
       __syncthreads();
+      if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[1] += tq1 - tq0; tq0 = tq1; }
       for (int e = tid; e < jb * jb; e += QP_T) {
         const int c1 = e / jb, c = e % jb;
         if (c > c1) L[(size_t)(J + c1) * ld + (J + c)] = U.Ld[c][c1];
       }
       if (tid < jb) Dg[J + tid] = U.dd[tid];
+      /* rows below the block: one column per iteration.  Branch-free body: rows that are not
+       * below the block read/write a private dummy cell (column stride 0), the column 8 ahead is
+       * prefetched into a register queue, and the (-w_j, -gamma) pairs are fetched half a column
+       * ahead of their use (two 8-rank buffers), so neither HBM nor LDS latency is exposed. */
+      bool any = false;
 #pragma unroll
-      for (int rr = 0; rr < RPT; rr++) {
-        const int i = tid + rr * QP_T;
-        if (i >= J + jb && i < n) {
-          for (int c1 = 0; c1 < jb; c1++) {
-            double l = L[(size_t)(J + c1) * ld + i];
+      for (int rr = 0; rr < RPT; rr++) { const int i = tid + rr * QP_T; any = any || (i >= J + jb && i < n); }
+      if (any) {
+        double *dummy = Wst + (size_t)QPG_KMAX * n;
+        double *rowp[RPT];
+        size_t cstride[RPT];
+        double q[RPT][8];
 #pragma unroll
-            for (int r = 0; r < K; r++) {
-              if (r < kk) {
-                w[rr][r] = QP_FMA(-U.cw[c1][r], l, w[rr][r]);
-                l = QP_FMA(-U.cg[c1][r], w[rr][r], l);
-              }
-            }
-            L[(size_t)(J + c1) * ld + i] = l;
+        for (int rr = 0; rr < RPT; rr++) {
+          const int i = tid + rr * QP_T;
+          const bool ok = (i >= J + jb && i < n);
+          rowp[rr] = ok ? (L + (size_t)J * ld + i) : (dummy + tid + rr * QP_T);
+          cstride[rr] = ok ? (size_t)ld : 0;
+#pragma unroll
+          for (int cc = 0; cc < 8; cc++) q[rr][cc] = rowp[rr][(size_t)((cc < jb) ? cc : jb - 1) * cstride[rr]];
+        }
+        constexpr int KH = (K + 1) / 2;
+        double ca[KH][2], cb[KH][2];
+#pragma unroll
+        for (int r = 0; r < KH; r++) { ca[r][0] = U.cwg[0][r][0]; ca[r][1] = U.cwg[0][r][1]; }
+#pragma unroll 1
+        for (int c1 = 0; c1 < jb; c1++) {
+          double l[RPT];
+          const int cpre = (c1 + 8 < jb) ? c1 + 8 : jb - 1;
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) {
+            l[rr] = q[rr][0];
+#pragma unroll
+            for (int cc = 0; cc < 7; cc++) q[rr][cc] = q[rr][cc + 1];
+            q[rr][7] = rowp[rr][(size_t)cpre * cstride[rr]];
           }
+#pragma unroll
+          for (int r = 0; r < K - KH; r++) { cb[r][0] = U.cwg[c1][KH + r][0]; cb[r][1] = U.cwg[c1][KH + r][1]; }
+          QP_SCHED_BARRIER();
+#pragma unroll
+          for (int r = 0; r < KH; r++) {
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) {
+              w[rr][r] = QP_FMA(ca[r][0], l[rr], w[rr][r]);
+              l[rr] = QP_FMA(ca[r][1], w[rr][r], l[rr]);
+            }
+          }
+          QP_SCHED_BARRIER();
+          const int cn = (c1 + 1 < NB) ? c1 + 1 : c1;
+#pragma unroll
+          for (int r = 0; r < KH; r++) { ca[r][0] = U.cwg[cn][r][0]; ca[r][1] = U.cwg[cn][r][1]; }
+          QP_SCHED_BARRIER();
+#pragma unroll
+          for (int r = 0; r < K - KH; r++) {
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) {
+              w[rr][KH + r] = QP_FMA(cb[r][0], l[rr], w[rr][KH + r]);
+              l[rr] = QP_FMA(cb[r][1], w[rr][KH + r], l[rr]);
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) rowp[rr][(size_t)c1 * cstride[rr]] = l[rr];
+          QP_SCHED_BARRIER();
         }
       }
       __syncthreads();
+      if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[2] += tq1 - tq0; tq0 = tq1; }
     }
   }
   __syncthreads();

@@ -239,11 +239,11 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
  * factorisation plumbing
  * =========================================================================================== */
 template <int RPT>
-QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds); }
+QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds, tdbg); }
 template <int RPT>
 QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *up, int n_up,
-                    const int *dn, int n_dn, QpShared &S, char *lds) {
-  dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V, b, L, Dg, Wst, up, n_up, dn, n_dn, S, lds);
+                    const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
+  dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V, b, L, Dg, Wst, up, n_up, dn, n_dn, S, lds, tdbg);
 }
 
 /* =============================================================================================
@@ -303,7 +303,7 @@ QPN void dev_update_sigma(const qpg_view &V, const QpArrays &a, int b, IterShare
       for (int e = a.Atp()[row]; e < a.Atp()[row + 1]; e++) a.Atss()[e] *= s;
     }
     __syncthreads();
-    dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds);
+    dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds, I.s.ticks_dbg);
     for (int k = tid; k < m; k += QP_T) {
       const double s = 1.0 / a.At_scale()[k];
       a.At_scale()[k] = s;
@@ -518,7 +518,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
   const qpg_settings &st = *V.settings;
   QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x;
-  double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * QPG_KMAX * n;
+  double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * V.wst_stride;
   __syncthreads();
   if (tid == 0) I.s = V.sc[b];
   __syncthreads();
@@ -537,6 +537,10 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       I.s.iter = 0; I.s.iter_out = 0; I.s.prev_iter = 0; I.s.no_change = 0;
       I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
       I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot;
+      I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
+      I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0;
+      I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
+      for (int k = 0; k < 8; k++) I.s.ticks_dbg[k] = 0;
     }
     __syncthreads();
   }
@@ -729,12 +733,14 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       const long long t0 = QP_CLOCK();
       if (action == 1) {
         form_schur<false>(V, b, L, true, prox != 0, gam, I.S, lds);
-        dev_factor<RPT>(V, L, Dg, lds);
+        if (tid == 0) I.s.ticks_dbg[3] += QP_CLOCK() - t0;
+        dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       } else if (action == 3) {
         form_schur<false>(V, b, L, false, prox != 0, gam, I.S, lds);
-        dev_factor<RPT>(V, L, Dg, lds);
+        if (tid == 0) I.s.ticks_dbg[3] += QP_CLOCK() - t0;
+        dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       } else if (action == 2) {
-        dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), I.s.nb_leave, I.S, lds);
+        dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), I.s.nb_leave, I.S, lds, I.s.ticks_dbg);
       }
       const long long t1 = QP_CLOCK();
       QP_OPAQUE(a.b);

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
   const qpg_settings &st = *V.settings;
   const QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x, slot = b;
-  double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * QPG_KMAX * n;
+  double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * V.wst_stride;
   if (tid == 0) I.s = V.sc[b];
   __syncthreads();
   switch (op) {
@@ -196,14 +196,14 @@ __global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
     case QP_OP_MATTVEC_A: spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
     case QP_OP_LDLCHOL:
       form_schur<false>(V, b, L, false, st.proximal != 0, I.s.gamma, I.S, lds);
-      dev_factor<RPT>(V, L, Dg, lds);
+      dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_LDLCHOL_QATSA:
       form_schur<false>(V, b, L, true, st.proximal != 0, I.s.gamma, I.S, lds);
-      dev_factor<RPT>(V, L, Dg, lds);
+      dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       break;
-    case QP_OP_UPDATE_ENTER: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), 0, I.S, lds); break;
-    case QP_OP_DOWNDATE_LEAVE: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), 0, a.leave(), I.s.nb_leave, I.S, lds); break;
+    case QP_OP_UPDATE_ENTER: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), 0, I.S, lds, I.s.ticks_dbg); break;
+    case QP_OP_DOWNDATE_LEAVE: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), 0, a.leave(), I.s.nb_leave, I.S, lds, I.s.ticks_dbg); break;
     case QP_OP_UPDATE_SIGMA: { /* solver_interface.c:443-503; At_scale and the changed list (enter) are set */
       const int nchg = I.s.nb_sigma_changed;
       for (int k = tid; k < nchg; k += QP_T) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
       __syncthreads();
       for (int k = tid; k < m; k += QP_T) { const double s = a.At_scale()[k]; if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s; }
       __syncthreads();
-      dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds);
+      dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds, I.s.ticks_dbg);
       for (int k = tid; k < m; k += QP_T) {
         const double s = 1.0 / a.At_scale()[k];
         a.At_scale()[k] = s;

@@ -51,11 +51,12 @@ typedef struct {
   /* work counters (device side statistics for the roofline accounting in bench.py) */
   int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_spmv;
   int64_t ticks_total, ticks_factor, ticks_update, ticks_solve, ticks_linesearch, ticks_resid;
+  int64_t ticks_dbg[8]; /* fine-grained phase timers (100 MHz ticks), see QPGStats.ms_dbg */
 } qpg_scalars;
 
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
-  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, pad1;
+  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride;
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.
    * Q: lower CSC.  Qf: both triangles (row == column compressed), with permutation into Q. */
   int32_t *Ap, *Ai, *Atp, *Ati, *Atperm, *Qp, *Qi, *Qfp, *Qfi, *Qfperm;
@@ -75,7 +76,7 @@ typedef struct {
   /* factor slots */
   double *L;   /* [nslots][ld*n] column-major, unit lower, strict lower part used */
   double *Dg;  /* [nslots][n] */
-  double *Wst; /* [nslots][QPG_KMAX][n] staging for rank-update vectors */
+  double *Wst; /* [nslots][wst_stride]: QPG_KMAX*n staging for rank-update vectors + a dummy row area */
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */
@@ -83,5 +84,6 @@ typedef struct {
 } qpg_view;
 
 #define QPG_KMAX 16
+#define QPG_DUMMY 4096 /* doubles per slot that masked-off rows load from / store to */
 
 #endif
