@@ -16,7 +16,8 @@
  *   qpg_batch_update_settings/bounds/q    qpalm_update_*    include/qpalm.h:95-126, src/qpalm.c:739-871
  *   qpg_batch_destroy                     qpalm_cleanup     include/qpalm.h:133,   src/qpalm.c:874-1096
  *   qpg_mat_vec / qpg_mat_tpose_vec       mat_vec / mat_tpose_vec          include/solver_interface.h:33,47
- *   qpg_ldlchol                           ldlchol                           include/solver_interface.h:172
+ *   qpg_ldlchol / qpg_ldlchol_matrix      ldlchol                           include/solver_interface.h:172
+ *   qpg_sparse_matvec                     mat_vec / mat_tpose_vec on a caller-owned matrix
  *   qpg_ldlcholQAtsigmaA                  ldlcholQAtsigmaA                  include/solver_interface.h:185
  *   qpg_ldlupdate_entering_constraints    ldlupdate_entering_constraints    include/solver_interface.h:196
  *   qpg_ldldowndate_leaving_constraints   ldldowndate_leaving_constraints   include/solver_interface.h:207
@@ -158,6 +159,11 @@ int  qpg_batch_sync(qpg_batch *bt);
 int qpg_mat_vec(qpg_batch *bt, qpg_int idx, int which /* 'A' or 'Q' */, const qpg_float *x, qpg_float *y);
 int qpg_mat_tpose_vec(qpg_batch *bt, qpg_int idx, int which, const qpg_float *x, qpg_float *y);
 int qpg_ldlchol(qpg_batch *bt, qpg_int idx);               /* factor Q (+ I/gamma if proximal) */
+/* ldlchol(M, work, c) for an arbitrary symmetric M given as CSC (lower triangle read), solver_interface.h:172 */
+int qpg_ldlchol_matrix(qpg_batch *bt, qpg_int idx, qpg_int n, const qpg_int *Mp, const qpg_int *Mi, const qpg_float *Mx);
+/* mat_vec / mat_tpose_vec for a caller-owned CSC matrix (stype 0, or -1/+1 = symmetric, one triangle stored) */
+int qpg_sparse_matvec(qpg_ctx *ctx, qpg_int nrow, qpg_int ncol, const qpg_int *Ap, const qpg_int *Ai, const qpg_float *Ax,
+                      int stype, int transpose, const qpg_float *x, qpg_float *y);
 int qpg_ldlcholQAtsigmaA(qpg_batch *bt, qpg_int idx);
 int qpg_ldlupdate_entering_constraints(qpg_batch *bt, qpg_int idx);
 int qpg_ldldowndate_leaving_constraints(qpg_batch *bt, qpg_int idx);

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libqpalm_gfx950.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libqpalm_gfx950_emu.so")
-_SRCS = ["qpalm_gfx950.hip", "qpalm_kernels.h", "qpalm_device.h", "qpalm_dense.h", "qpalm_iter.h", "qpalm_types.h",
+_SRCS = ["../host/qpalm_host.c", "qpalm_gfx950.hip", "qpalm_kernels.h", "qpalm_device.h", "qpalm_dense.h", "qpalm_iter.h", "qpalm_types.h",
          "qpalm_capi.inc"]
 
 
@@ -34,7 +34,18 @@ def build_hip(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_host()
     return LIB
+
+
+def build_host():
+    """The C host library (reference API names, include/qpalm_host.h) on top of the HIP library."""
+    out = os.path.join(HERE, "lib", "libqpalm.so")
+    libdir = os.path.dirname(LIB)
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-o", out,
+                           os.path.join(HERE, "host", "qpalm_host.c"), "-L" + libdir, "-lqpalm_gfx950",
+                           "-Wl,-rpath,$ORIGIN", "-lm"])
+    return out
 
 
 def build_emu(force=False, block=128):

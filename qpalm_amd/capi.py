@@ -106,6 +106,8 @@ def load(path=None):
               "qpg_compute_residuals", "qpg_set_active_constraints"):
         getattr(L, f).argtypes = [C.c_void_p, c_int]
     L.qpg_exact_linesearch.argtypes = [C.c_void_p, c_int, pf]
+    L.qpg_ldlchol_matrix.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf]
+    L.qpg_sparse_matvec.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf, C.c_int, C.c_int, pf, pf]
     L.qpg_batch_ldlsolve_all.argtypes = [C.c_void_p, c_int, C.POINTER(C.c_float)]
     _LIBS[path] = L
     return L
@@ -122,7 +124,7 @@ SYMBOLS = [
     "qpg_batch_destroy", "qpg_batch_device_ptr", "qpg_batch_sync", "qpg_mat_vec", "qpg_mat_tpose_vec", "qpg_ldlchol",
     "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints", "qpg_ldldowndate_leaving_constraints",
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
-    "qpg_exact_linesearch", "qpg_batch_ldlsolve_all",
+    "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
 ]
 
 

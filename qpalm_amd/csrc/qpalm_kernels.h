@@ -21,6 +21,7 @@
 #define QP_OP_RESIDUALS 10
 #define QP_OP_ACTIVE 11
 #define QP_OP_LINESEARCH 12
+#define QP_OP_FACTOR_LOADED 13
 
 /* qpalm_setup's device part: Ruiz scaling (scaling.c:34-113) and derived copies.
  * mode 0: fresh setup (nscale iterations); mode 1: qpalm_update_settings with more scaling
@@ -198,6 +199,11 @@ __global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
       form_schur<false>(V, b, L, false, st.proximal != 0, I.s.gamma, I.S, lds);
       dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       break;
+    case QP_OP_FACTOR_LOADED: /* the host wrote a symmetric matrix (lower triangle) into the slot */
+      if (st.proximal) for (int j = tid; j < n; j += QP_T) L[(size_t)j * V.ld + j] += 1.0 / I.s.gamma;
+      __syncthreads();
+      dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
+      break;
     case QP_OP_LDLCHOL_QATSA:
       form_schur<false>(V, b, L, true, st.proximal != 0, I.s.gamma, I.S, lds);
       dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
@@ -235,6 +241,11 @@ __global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
   }
   __syncthreads();
   if (tid == 0) V.sc[b] = I.s;
+}
+
+/* y = Op x for a caller-owned operator given by its compressed rows (boundary mat_vec) */
+__global__ __launch_bounds__(QP_T) void k_spmv_generic(int nrows, const int *ptr, const int *idx, const double *val, const double *x, double *y) {
+  spmv_rows<8>(nrows, ptr, idx, val, x, [&](int r, double s) { y[r] = s; });
 }
 
 /* Every QP of the batch: d = -(L D L')^{-1} dphi with its current factor, `reps` times.  This is

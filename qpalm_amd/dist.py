@@ -1,0 +1,64 @@
+"""Multi-GPU batch sharding.
+
+QPs are independent units: a batch is partitioned over the ranks of one node (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests), every rank
+solves its shard with no data-path collective, and ONE gather at the end brings solution.x,
+solution.y and the info records to rank 0.  A single QP is never split across GPUs.
+"""
+import numpy as np
+
+INFO_FIELDS = ("iter", "iter_out", "status_val", "pri_res_norm", "dua_res_norm", "dua2_res_norm", "objective")
+
+
+def shard_indices(nqp, world, rank):
+    """Round-robin assignment: per-instance cost varies by >10x inside one problem family
+    (simulations/results/journal_paper/randomMPCsequential2.tex:32-61), so contiguous shards are
+    avoided; rank r owns QPs r, r + world, ..."""
+    return np.arange(rank, nqp, world)
+
+
+def pack_info(batch):
+    out = np.zeros((batch.B, len(INFO_FIELDS)))
+    for b in range(batch.B):
+        info = batch.info(b)
+        out[b] = [float(getattr(info, k)) for k in INFO_FIELDS]
+    return out
+
+
+def solve_sharded(problems, make_batch, dist=None, device=None):
+    """Solve `problems` (the full list, same on every rank) sharded over the process group.
+    make_batch(list_of_problems) -> QpalmBatch.  Returns (x, y, info) on rank 0, None elsewhere."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    nqp = len(problems)
+    mine = shard_indices(nqp, world, rank)
+    n, m = problems[0].n, problems[0].m
+    if len(mine):
+        bt = make_batch([problems[i] for i in mine])
+        bt.solve()
+        x, y = bt.solution()
+        info = pack_info(bt)
+    else:
+        x, y, info = np.zeros((0, n)), np.zeros((0, m)), np.zeros((0, len(INFO_FIELDS)))
+    if world == 1:
+        return x, y, info
+    # equal padded shards so that one gather moves everything (24 KB per QP at n=1000, m=2000)
+    per = (nqp + world - 1) // world
+    payload = np.zeros((per, n + m + len(INFO_FIELDS)))
+    payload[:len(mine), :n] = x
+    payload[:len(mine), n:n + m] = y
+    payload[:len(mine), n + m:] = info
+    t = torch.from_numpy(payload)
+    if device is not None:
+        t = t.to(device)
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, bufs, dst=0)
+    if rank != 0:
+        return None
+    X, Y, I = np.zeros((nqp, n)), np.zeros((nqp, m)), np.zeros((nqp, len(INFO_FIELDS)))
+    for r in range(world):
+        idx = shard_indices(nqp, world, r)
+        blk = bufs[r].cpu().numpy()[:len(idx)]
+        X[idx], Y[idx], I[idx] = blk[:, :n], blk[:, n:n + m], blk[:, n + m:]
+    return X, Y, I

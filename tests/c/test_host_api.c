@@ -1,0 +1,169 @@
+/*
+ * test_host_api.c -- the reference's C test-suites (tests/src/test_basic_qp.c, test_degen_hess.c,
+ * test_update.c, test_prim_inf_qp.c, test_dua_inf_qp.c, test_solver_interface.c) restated against
+ * include/qpalm_host.h, i.e. through qpalm_setup()/qpalm_solve()/QPALMWorkspace exactly as a user of
+ * the reference would call them.  Problem data and expected values come from the golden fixture
+ * (golden_data.h is generated from tests/golden/reference_tests.json by tests/test_host_c_api.py).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/qpalm_host.h"
+#include "golden_data.h"
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond) do { g_checks++; if (!(cond)) { g_fail++; printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); } } while (0)
+#define CHECK_NEAR(a, b, tol) do { g_checks++; if (!(fabs((a) - (b)) <= (tol))) { g_fail++; printf("FAIL %s:%d: %s=%.15g vs %.15g (tol %g)\n", __FILE__, __LINE__, #a, (double)(a), (double)(b), (double)(tol)); } } while (0)
+
+static QPALMData *make_data(const golden_problem *g) {
+  QPALMData *d = (QPALMData *)calloc(1, sizeof(QPALMData));
+  d->n = g->n; d->m = g->m; d->c = 0;
+  d->A = qpalm_sparse_alloc(g->m, g->n, g->nnzA ? g->nnzA : 1, 0);
+  d->Q = qpalm_sparse_alloc(g->n, g->n, g->nnzQ ? g->nnzQ : 1, -1);
+  memcpy(d->A->p, g->Ap, (g->n + 1) * sizeof(c_int)); memcpy(d->A->i, g->Ai, g->nnzA * sizeof(c_int)); memcpy(d->A->x, g->Ax, g->nnzA * sizeof(c_float));
+  memcpy(d->Q->p, g->Qp, (g->n + 1) * sizeof(c_int)); memcpy(d->Q->i, g->Qi, g->nnzQ * sizeof(c_int)); memcpy(d->Q->x, g->Qx, g->nnzQ * sizeof(c_float));
+  d->q = (c_float *)malloc(g->n * sizeof(c_float)); memcpy(d->q, g->q, g->n * sizeof(c_float));
+  d->bmin = (c_float *)malloc(g->m * sizeof(c_float)); memcpy(d->bmin, g->bmin, g->m * sizeof(c_float));
+  d->bmax = (c_float *)malloc(g->m * sizeof(c_float)); memcpy(d->bmax, g->bmax, g->m * sizeof(c_float));
+  return d;
+}
+static void free_data(QPALMData *d) { qpalm_sparse_free(&d->A); qpalm_sparse_free(&d->Q); free(d->q); free(d->bmin); free(d->bmax); free(d); }
+
+/* suite_basic_qp (tests/src/test_basic_qp.c:90-427) */
+static void basic_defaults(QPALMSettings *s) {
+  qpalm_set_default_settings(s);
+  s->max_rank_update_fraction = 1.0; s->verbose = 0;
+  s->eps_abs = 1e-6; s->eps_rel = 1e-6; s->gamma_init = 1e1;
+}
+static void check_basic_solution(QPALMWorkspace *work) {
+  CHECK(work->info->status_val == QPALM_SOLVED);
+  for (int i = 0; i < 4; i++) CHECK_NEAR(work->solution->x[i], basic_qp_solution[i], fabs(1e-5 * basic_qp_solution[i]));
+}
+static void suite_basic_qp(void) {
+  QPALMData *data = make_data(&golden_basic_qp);
+  QPALMSettings s;
+  QPALMWorkspace *work;
+  basic_defaults(&s); work = qpalm_setup(data, &s); CHECK(work != QPALM_NULL); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
+  basic_defaults(&s); s.scaling = 0; work = qpalm_setup(data, &s); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
+  basic_defaults(&s); s.proximal = FALSE; s.scaling = 2; work = qpalm_setup(data, &s); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
+  basic_defaults(&s); s.proximal = FALSE; s.scaling = 0; work = qpalm_setup(data, &s); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
+  { /* test_basic_qp_warm_start */
+    c_float x[4] = {2.0, -60.0, -3380.0, -6.0}, y[5] = {0.0, 0.0, -23.0, -0.014, 0.0};
+    basic_defaults(&s); s.scaling = 2; s.warm_start = TRUE;
+    work = qpalm_setup(data, &s); qpalm_warm_start(work, x, y); qpalm_solve(work);
+    CHECK(work->info->iter < 12); check_basic_solution(work); qpalm_cleanup(work);
+  }
+  { /* test_basic_qp_warm_start_resolve: identical to 1e-15, same iteration count */
+    c_float x[4], y[5], xs[4], ys[5];
+    basic_defaults(&s); work = qpalm_setup(data, &s);
+    memcpy(x, work->x, sizeof x); memcpy(y, work->y, sizeof y);
+    qpalm_solve(work); CHECK(work->info->status_val == QPALM_SOLVED);
+    memcpy(xs, work->solution->x, sizeof xs); memcpy(ys, work->solution->y, sizeof ys);
+    c_int iter = work->info->iter;
+    qpalm_warm_start(work, x, y); qpalm_solve(work);
+    CHECK(work->info->iter == iter);
+    for (int i = 0; i < 4; i++) CHECK_NEAR(work->solution->x[i], xs[i], 1e-15);
+    for (int i = 0; i < 5; i++) CHECK_NEAR(work->solution->y[i], ys[i], 1e-15);
+    qpalm_cleanup(work);
+  }
+  basic_defaults(&s); s.max_iter = 1; work = qpalm_setup(data, &s); qpalm_solve(work); CHECK(work->info->status_val == QPALM_MAX_ITER_REACHED); qpalm_cleanup(work);
+  basic_defaults(&s); s.eps_abs = 1e-8; s.eps_rel = 1e-8; s.inner_max_iter = 2; s.max_iter = 10;
+  work = qpalm_setup(data, &s); qpalm_solve(work); CHECK(work->info->status_val == QPALM_MAX_ITER_REACHED); qpalm_cleanup(work);
+  basic_defaults(&s); s.sigma_max = 1e3; work = qpalm_setup(data, &s); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
+  basic_defaults(&s); s.time_limit = 0.01 * 1e-3; work = qpalm_setup(data, &s); qpalm_solve(work); CHECK(work->info->status_val == QPALM_TIME_LIMIT_REACHED); qpalm_cleanup(work);
+  free_data(data);
+}
+
+/* suite_degen_hess (tests/src/test_degen_hess.c:95-105) */
+static void suite_degen_hess(void) {
+  QPALMData *data = make_data(&golden_degen_hess);
+  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.max_rank_update_fraction = 1.0; s.verbose = 0;
+  QPALMWorkspace *work = qpalm_setup(data, &s);
+  qpalm_solve(work);
+  CHECK(work->info->status_val == QPALM_SOLVED);
+  CHECK_NEAR(work->solution->x[0], 5.5, 1e-5); CHECK_NEAR(work->solution->x[1], 5, 1e-5); CHECK_NEAR(work->solution->x[2], -10, 1e-5);
+  qpalm_cleanup(work); free_data(data);
+}
+
+/* suite_prim_inf_qp / suite_dua_inf_qp */
+static void suite_infeasible(void) {
+  for (int which = 0; which < 2; which++) {
+    QPALMData *data = make_data(which ? &golden_dua_inf_qp : &golden_prim_inf_qp);
+    const int prox[4] = {1, 1, 0, 0}, scal[4] = {2, 0, 2, 0};
+    for (int k = 0; k < 4; k++) {
+      QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.max_rank_update_fraction = 1.0; s.verbose = 0;
+      s.proximal = prox[k]; s.scaling = scal[k];
+      QPALMWorkspace *work = qpalm_setup(data, &s); qpalm_solve(work);
+      CHECK(work->info->status_val == (which ? QPALM_DUAL_INFEASIBLE : QPALM_PRIMAL_INFEASIBLE));
+      qpalm_cleanup(work);
+    }
+    free_data(data);
+  }
+}
+
+/* suite_update (tests/src/test_update.c:91-148): three tests on one workspace */
+static void suite_update(void) {
+  QPALMData *data = make_data(&golden_update);
+  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.scaling = 2; s.proximal = TRUE; s.verbose = 0;
+  QPALMWorkspace *work = qpalm_setup(data, &s);
+  qpalm_solve(work);
+  CHECK(work->info->status_val == QPALM_SOLVED); CHECK_NEAR(work->solution->x[0], -0.1, 1e-5); CHECK_NEAR(work->solution->x[1], 0.3, 1e-5);
+  s.gamma_init *= 0.1; s.theta = 0.9; s.proximal = TRUE; s.scaling = 10;
+  qpalm_update_settings(work, &s); CHECK(work->info->status_val != QPALM_ERROR);
+  qpalm_solve(work);
+  CHECK(work->info->status_val == QPALM_SOLVED); CHECK_NEAR(work->solution->x[0], -0.1, 1e-5); CHECK_NEAR(work->solution->x[1], 0.3, 1e-5);
+  data->bmin[0] = 0.0; data->bmax[1] = 1.5;
+  qpalm_update_bounds(work, data->bmin, data->bmax); qpalm_solve(work);
+  CHECK(work->info->status_val == QPALM_SOLVED); CHECK_NEAR(work->solution->x[0], 0.0, 1e-5); CHECK_NEAR(work->solution->x[1], 0.15, 1e-5);
+  data->bmin[0] = -1; data->bmax[1] = 3; qpalm_update_bounds(work, data->bmin, data->bmax);
+  data->q[0] = -0.5; data->q[1] = -0.75; qpalm_update_q(work, data->q); qpalm_solve(work);
+  CHECK(work->info->status_val == QPALM_SOLVED); CHECK_NEAR(work->solution->x[0], 0.02, 1e-5); CHECK_NEAR(work->solution->x[1], 0.18, 1e-5);
+  /* error handling (tests/src/test_error_handling.c:99-134) */
+  s.max_iter = -10; qpalm_update_settings(work, &s); CHECK(work->info->status_val == QPALM_ERROR);
+  qpalm_cleanup(work);
+  s.max_iter = -1; CHECK(qpalm_setup(data, &s) == QPALM_NULL);
+  free_data(data);
+}
+
+/* suite_solver (tests/src/test_solver_interface.c:106-160) */
+static void suite_solver(void) {
+  QPALMData *data = make_data(&golden_solver_interface);
+  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.verbose = 0;
+  QPALMWorkspace *work = qpalm_setup(data, &s);
+  solver_common common, *c = &common;
+  const double TOL = 1e-8;
+  work->Qd[0] = 1.1; work->Qd[1] = -0.5; work->Ad[0] = 1.1; work->Ad[1] = -0.5; work->Ad[2] = 20;
+  mat_vec(data->A, work->solver->Qd, work->solver->Ad, c);
+  CHECK_NEAR(work->Ad[0], 0.1, TOL); CHECK_NEAR(work->Ad[1], 1.3, TOL); CHECK_NEAR(work->Ad[2], 5.5, TOL);
+  mat_vec(data->Q, work->solver->Qd, work->solver->Qd, c); /* aliased */
+  CHECK_NEAR(work->Qd[0], 1.6, TOL); CHECK_NEAR(work->Qd[1], -2.1, TOL);
+  work->Qd[0] = 1.1; work->Qd[1] = -0.5;
+  mat_tpose_vec(data->Q, work->solver->Qd, work->solver->Qd, c);
+  CHECK_NEAR(work->Qd[0], 1.6, TOL); CHECK_NEAR(work->Qd[1], -2.1, TOL);
+  work->Ad[0] = 1.1; work->Ad[1] = -0.5; work->Ad[2] = 20;
+  mat_tpose_vec(data->A, work->solver->Ad, work->solver->Qd, c);
+  CHECK_NEAR(work->Qd[0], 99.6, TOL); CHECK_NEAR(work->Qd[1], 0.2, TOL);
+  c_float cols[2], rows[3];
+  mat_inf_norm_cols(data->A, cols); mat_inf_norm_rows(data->A, rows);
+  CHECK_NEAR(cols[0], 5.0, TOL); CHECK_NEAR(cols[1], 4.0, TOL); CHECK_NEAR(rows[0], 2.0, TOL); CHECK_NEAR(rows[1], 4.0, TOL); CHECK_NEAR(rows[2], 5.0, TOL);
+  /* test_ldlchol: the USER's Q, with and without the proximal term */
+  work->settings->proximal = FALSE; work->dphi[0] = -1.0; work->dphi[1] = -2.0;
+  ldlchol(data->Q, work, c); ldlsolveLD_neg_dphi(work, c);
+  CHECK_NEAR(work->d[0], 4.0, TOL); CHECK_NEAR(work->d[1], 3.0, TOL);
+  work->settings->proximal = TRUE; work->gamma = 1e3;
+  ldlchol(data->Q, work, c); ldlsolveLD_neg_dphi(work, c);
+  CHECK_NEAR(work->d[0], 3.989028924198480, TOL); CHECK_NEAR(work->d[1], 2.993017953122679, TOL);
+  qpalm_cleanup(work); free_data(data);
+}
+
+int main(void) {
+  suite_solver();
+  suite_basic_qp();
+  suite_degen_hess();
+  suite_infeasible();
+  suite_update();
+  printf("%d checks, %d failures\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}
