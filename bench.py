@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dbg-flags", type=int, default=0, help="timing experiments only (results wrong)")
     args = ap.parse_args()
 
     import torch
@@ -109,6 +110,8 @@ def main():
     from qpalm_amd.solver import Context, QpalmBatch
     ctx = Context(local)
     ctx.set_option("update_rank_threshold", args.rank_threshold)
+    if args.dbg_flags:
+        ctx.set_option("dbg_flags", args.dbg_flags)
     B, n, m = args.batch, args.n, args.m
     settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     dens_A = 0.01 if n >= 400 else max(0.01, 4.0 / n)

@@ -25,6 +25,16 @@
 #define QP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
+
+#ifdef QPALM_EMU
+QPD double qp_readlane(double v, int src) { return emu_exchange(v, src); }
+#else
+QPD double qp_readlane(double v, int src) { /* src is wave-uniform: v_readlane_b32 x2, result lives in SGPRs */
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+#endif
+
 /* ---------------------------------------------------------------------------------------------
  * form_schur: H(:,j) for j = 0..n-1, lower triangle, written into the factor slot.
  *   H_ij = Q_ij + sum_{t active} F_it F_jt (+ 1/gamma on the diagonal), F = At_sqrt_sigma.
@@ -41,6 +51,7 @@ QPN double form_schur(const qpg_view &V, int b, double *Lslot, bool with_AtSA, b
   const int *Ap = V.Ap + (size_t)b * (n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
+  const int *Ainv = V.Ainv + (size_t)b * V.nnzA;
   const int *Qp = V.Qp + (size_t)b * (n + 1), *Qi = V.Qi + (size_t)b * V.nnzQ;
   const double *Qx = V.Qx + (size_t)b * V.nnzQ;
   const int *active = V.active + (size_t)b * V.m;
@@ -61,15 +72,7 @@ QPN double form_schur(const qpg_view &V, int b, double *Lslot, bool with_AtSA, b
           const int t = Ai[p];
           if (!active[t]) continue;
           const int k0 = Atp[t], k1 = Atp[t + 1];
-          /* find F_jt */
-          double vj = 0.0;
-          for (int kb = k0; kb < k1; kb += 64) {
-            const int k = kb + lane;
-            const int hit = (k < k1) && (Ati[k] == j);
-            const unsigned long long bal = __ballot(hit);
-            const double cand = __shfl((k < k1) ? Atss[k] : 0.0, bal ? (__ffsll(bal) - 1) : 0);
-            if (bal) vj = cand;
-          }
+          const double vj = Atss[Ainv[p]]; /* F_jt: the entry of column t of A' that sits in row j */
           for (int kb = k0; kb < k1; kb += 64) {
             const int k = kb + lane;
             if (k < k1) {
@@ -297,11 +300,15 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
       if (r > c) T.tile[r][c] = L[(size_t)(J + c) * ld + (J + r)];
     }
     __syncthreads();
-    if (wid == 0) {
+    if (wid == 0) { /* lane = row of the block; its row of L in registers, pivots broadcast by readlane */
       double v = (lane < jb) ? xs[J + lane] : 0.0;
-      for (int c = 0; c < jb; c++) {
-        const double yc = __shfl(v, c);
-        if (lane > c && lane < jb) v = QP_FMA(-T.tile[lane][c], yc, v);
+      double trow[QP_SNB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) trow[c] = (lane < jb && c < lane) ? T.tile[lane][c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        const double yc = qp_readlane(v, c);
+        v = QP_FMA(-trow[c], yc, v);
       }
       if (lane < jb) xs[J + lane] = v;
     }
@@ -338,11 +345,15 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
       if (r > c) T.tile[r][c] = L[(size_t)(J + c) * ld + (J + r)];
     }
     __syncthreads();
-    if (wid == 0) {
+    if (wid == 0) { /* lane = column of the block: holds L(J+c, J+lane) for c > lane */
       double v = (lane < jb) ? (xs[J + lane] - T.part[lane]) : 0.0;
-      for (int c = jb - 1; c >= 0; c--) {
-        const double xc = __shfl(v, c);
-        if (lane < c) v = QP_FMA(-T.tile[c][lane], xc, v);
+      double tcol[QP_SNB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) tcol[c] = (c < jb && lane < c) ? T.tile[c][lane] : 0.0;
+#pragma unroll
+      for (int c = NB - 1; c >= 0; c--) {
+        const double xc = qp_readlane(v, c);
+        v = QP_FMA(-tcol[c], xc, v);
       }
       if (lane < jb) xs[J + lane] = v;
     }
@@ -466,13 +477,16 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
             const double d0 = U.dd[c1];
             const double p = sg * wv * wv * ialpha;
             double incl = p;
+            if (!(V.dbg_flags & 4)) {
             if (K > 1) incl += qp_row_shr<1>(incl);
             if (K > 2) incl += qp_row_shr<2>(incl);
             if (K > 4) incl += qp_row_shr<4>(incl);
             if (K > 8) incl += qp_row_shr<8>(incl);
+            }
             const double excl = qp_row_shr<1>(incl);
             const double dnew = d0 + incl, dprev = d0 + excl;
-            const double rdn = 1.0 / dnew, rdp = 1.0 / dprev;
+            const int dbgf = V.dbg_flags;
+            const double rdn = (dbgf & 1) ? dnew : 1.0 / dnew, rdp = (dbgf & 1) ? dprev : 1.0 / dprev;
             const double gam = -sg * wv * ialpha * rdn;
             if (lane < K) { U.cwg[c1][lane][0] = -wv; U.cwg[c1][lane][1] = -gam; } /* stored negated: plain FMAs below */
             alpha = alpha * dnew * rdp;
@@ -481,7 +495,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
             QP_WAVE_SYNC();
             /* rows of the block: lane = row; all K coefficient pairs are fetched first, then the
              * l chain is one FMA per rank: l <- (1 + g w_j) l - g w_r ; w_r <- w_r - w_j l_r */
-            {
+            if (!(V.dbg_flags & 2)) {
               double l = lcur;
 #pragma unroll
               for (int rb = 0; rb < K; rb += 8) {

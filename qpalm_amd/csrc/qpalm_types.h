@@ -56,10 +56,10 @@ typedef struct {
 
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
-  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride;
+  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, dbg_flags, pad2;
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.
    * Q: lower CSC.  Qf: both triangles (row == column compressed), with permutation into Q. */
-  int32_t *Ap, *Ai, *Atp, *Ati, *Atperm, *Qp, *Qi, *Qfp, *Qfi, *Qfperm;
+  int32_t *Ap, *Ai, *Atp, *Ati, *Atperm, *Ainv, *Qp, *Qi, *Qfp, *Qfi, *Qfperm; /* Ainv: position in A' of every entry of A */
   double *Ax, *Atx, *Atss, *Qx, *Qfx;
   double *q, *bmin, *bmax, *c0;
   /* iterates / work vectors */
