@@ -61,7 +61,8 @@ _LIBS = {}
 
 
 def load(path=None):
-    path = path or LIB_PATH
+    # QPALM_GFX950_LIB: A/B benchmarking of two HIP builds on one box (never a fallback: still a HIP library)
+    path = path or os.environ.get("QPALM_GFX950_LIB") or LIB_PATH
     if path in _LIBS:
         return _LIBS[path]
     if not os.path.exists(path):

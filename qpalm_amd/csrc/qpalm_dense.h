@@ -28,10 +28,25 @@
 
 #ifdef QPALM_EMU
 QPD double qp_readlane(double v, int src) { return emu_exchange(v, src); }
+QPD int qp_readlane_i(int v, int src) { return emu_exchange(v, src); }
 #else
+QPD int qp_readlane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 QPD double qp_readlane(double v, int src) { /* src is wave-uniform: v_readlane_b32 x2, result lives in SGPRs */
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
+}
+#endif
+
+/* 1/x to (almost) full fp64 precision: v_rcp_f64 + two Newton steps; avoids the ~28-instruction
+ * IEEE division sequence on the serial chain of the update recurrence */
+#ifdef QPALM_EMU
+QPD double qp_rcp(double x) { return 1.0 / x; }
+#else
+QPD double qp_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = QP_FMA(QP_FMA(-x, r, 1.0), r, r);
+  r = QP_FMA(QP_FMA(-x, r, 1.0), r, r);
+  return r;
 }
 #endif
 
@@ -68,19 +83,47 @@ QPN double form_schur(const qpg_view &V, int b, double *Lslot, bool with_AtSA, b
       for (int i = lo + lane; i < n; i += 64) buf[i] = 0.0;
       QP_WAVE_SYNC();
       if (with_AtSA) {
-        for (int p = Ap[j]; p < Ap[j + 1]; p++) {
-          const int t = Ai[p];
-          if (!active[t]) continue;
-          const int k0 = Atp[t], k1 = Atp[t + 1];
-          const double vj = Atss[Ainv[p]]; /* F_jt: the entry of column t of A' that sits in row j */
-          for (int kb = k0; kb < k1; kb += 64) {
-            const int k = kb + lane;
-            if (k < k1) {
-              const int i = Ati[k];
-              if (i >= lo) buf[i] += Atss[k] * vj;
+        /* Global latency (~0.5 us per dependent load) dominates this walk, so the metadata of up to
+         * 64 rows t of A(:,j) is fetched in ONE round trip (lane = entry of the column) and the
+         * entries of F(:,t) are fetched for four active rows at a time; the adds into the column
+         * buffer stay sequential in t (ascending), which keeps the sums deterministic. */
+        const int p0 = Ap[j], p1 = Ap[j + 1];
+        for (int pb = p0; pb < p1; pb += 64) {
+          const int pidx = pb + lane;
+          const bool valid = pidx < p1;
+          const int t_l = valid ? Ai[pidx] : 0;
+          const int act_l = valid ? active[t_l] : 0;
+          int k0_l = 0, cnt_l = 0;
+          double vj_l = 0.0;
+          if (act_l) { k0_l = Atp[t_l]; cnt_l = Atp[t_l + 1] - k0_l; vj_l = Atss[Ainv[pidx]]; }
+          unsigned long long mask = __ballot(act_l);
+          while (mask) {
+            int sl[4], cn[4], kk0[4], ig[4];
+            double vg[4], vjg[4];
+            int ng = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              sl[g] = mask ? (__ffsll(mask) - 1) : 0;
+              if (mask) { ng = g + 1; mask &= mask - 1; }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              kk0[g] = qp_readlane_i(k0_l, sl[g]); cn[g] = (g < ng) ? qp_readlane_i(cnt_l, sl[g]) : 0; vjg[g] = qp_readlane(vj_l, sl[g]);
+              ig[g] = 0; vg[g] = 0.0;
+              if (lane < cn[g]) { ig[g] = Ati[kk0[g] + lane]; vg[g] = Atss[kk0[g] + lane]; }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              if (g < ng) {
+                if (lane < cn[g] && ig[g] >= lo) buf[ig[g]] += vg[g] * vjg[g];
+                for (int kb = 64; kb < cn[g]; kb += 64) { /* rows of A with more than 64 entries */
+                  const int k = kb + lane;
+                  if (k < cn[g]) { const int i = Ati[kk0[g] + k]; if (i >= lo) buf[i] += Atss[kk0[g] + k] * vjg[g]; }
+                }
+                QP_WAVE_SYNC();
+              }
             }
           }
-          QP_WAVE_SYNC();
         }
       }
       if (!GERSH) {
@@ -135,10 +178,10 @@ struct FactorLds {
  * (tile index J/16 + wid + NW*t): branch-free k loop, fragments of step k+4 are in flight while the
  * 2*NTJ MFMAs of step k execute. */
 template <int NTJ>
-QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J) {
+QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J, int tbase) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int tile0 = J / 16 + wid;
+  const int tile0 = J / 16 + tbase + wid;
   qp_double4 acc[NTJ][2];
   int rowc[NTJ];
 #pragma unroll
@@ -154,32 +197,41 @@ QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J) 
       }
   }
   const int rowp0 = (J + l15 < n) ? (J + l15) : (n - 1), rowp1 = (J + 16 + l15 < n) ? (J + 16 + l15) : (n - 1);
-  if (J > 0) {
-    double pa0, pa1, bv[NTJ];
-    {
-      const double *colk = L + (size_t)l4 * ld;
-      const double dk = Dg[l4];
-      pa0 = -(colk[rowp0] * dk); pa1 = -(colk[rowp1] * dk);
+  if (J > 0) { /* J is a multiple of 32: eight columns of L per iteration, the next eight already in flight */
+    double pa[2][2], bv[2][NTJ];
 #pragma unroll
-      for (int t = 0; t < NTJ; t++) bv[t] = colk[rowc[t]];
+    for (int h = 0; h < 2; h++) {
+      const double *colk = L + (size_t)(4 * h + l4) * ld;
+      const double dk = Dg[4 * h + l4];
+      pa[h][0] = -(colk[rowp0] * dk); pa[h][1] = -(colk[rowp1] * dk);
+#pragma unroll
+      for (int t = 0; t < NTJ; t++) bv[h][t] = colk[rowc[t]];
     }
 #pragma unroll 1
-    for (int k = 0; k < J; k += 4) {
-      const int kn = (k + 4 < J) ? (k + 4) : k; /* last step re-reads its own fragments */
-      const double *colk = L + (size_t)(kn + l4) * ld;
-      const double dk = Dg[kn + l4];
-      const double na0 = colk[rowp0], na1 = colk[rowp1];
-      double nb[NTJ];
+    for (int k = 0; k < J; k += 8) {
+      const int kn = (k + 8 < J) ? (k + 8) : k; /* last iteration re-reads its own fragments */
+      double na[2][2], nb[2][NTJ], nd[2];
 #pragma unroll
-      for (int t = 0; t < NTJ; t++) nb[t] = colk[rowc[t]];
+      for (int h = 0; h < 2; h++) {
+        const double *colk = L + (size_t)(kn + 4 * h + l4) * ld;
+        nd[h] = Dg[kn + 4 * h + l4];
+        na[h][0] = colk[rowp0]; na[h][1] = colk[rowp1];
 #pragma unroll
-      for (int t = 0; t < NTJ; t++) {
-        acc[t][0] = QP_MFMA_F64(pa0, bv[t], acc[t][0]);
-        acc[t][1] = QP_MFMA_F64(pa1, bv[t], acc[t][1]);
+        for (int t = 0; t < NTJ; t++) nb[h][t] = colk[rowc[t]];
       }
-      pa0 = -(na0 * dk); pa1 = -(na1 * dk);
 #pragma unroll
-      for (int t = 0; t < NTJ; t++) bv[t] = nb[t];
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int t = 0; t < NTJ; t++) {
+          acc[t][0] = QP_MFMA_F64(pa[h][0], bv[h][t], acc[t][0]);
+          acc[t][1] = QP_MFMA_F64(pa[h][1], bv[h][t], acc[t][1]);
+        }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        pa[h][0] = -(na[h][0] * nd[h]); pa[h][1] = -(na[h][1] * nd[h]);
+#pragma unroll
+        for (int t = 0; t < NTJ; t++) bv[h][t] = nb[h][t];
+      }
     }
   }
 #pragma unroll
@@ -198,27 +250,25 @@ QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J) 
 }
 
 template <int RPT>
-QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *tdbg) {
+QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *tdbg, int dbgf = 0) {
   FactorLds &F = *(FactorLds *)lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_FNB;
-  constexpr int NT = (RPT * QP_T / 16 + QP_NW - 1) / QP_NW; /* 16-row tiles per wavefront, at most */
   __syncthreads();
   long long tq0 = QP_CLOCK();
   for (int J = 0; J < n; J += NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
-    /* ---- (1) panel update on the matrix cores ------------------------------------------------ */
+    /* ---- (1) panel update on the matrix cores: passes of at most 4 row tiles per wavefront ---- */
     {
       const int ntiles = (n - J + 15) / 16;
-      const int ntj = (ntiles + QP_NW - 1) / QP_NW; /* same for every wavefront */
-      if (ntj <= 1) factor_panel_update<1>(L, Dg, n, ld, J);
-      else if (ntj == 2) factor_panel_update<(NT >= 2 ? 2 : 1)>(L, Dg, n, ld, J);
-      else if (ntj == 3) factor_panel_update<(NT >= 3 ? 3 : 1)>(L, Dg, n, ld, J);
-      else if (ntj == 4) factor_panel_update<(NT >= 4 ? 4 : 1)>(L, Dg, n, ld, J);
-      else if (ntj <= 6) factor_panel_update<(NT >= 6 ? 6 : 1)>(L, Dg, n, ld, J);
-      else if (ntj <= 8) factor_panel_update<(NT >= 8 ? 8 : 1)>(L, Dg, n, ld, J);
-      else if (ntj <= 12) factor_panel_update<(NT >= 12 ? 12 : 1)>(L, Dg, n, ld, J);
-      else factor_panel_update<(NT >= 16 ? 16 : 1)>(L, Dg, n, ld, J);
+      for (int tbase = 0; tbase < ntiles; tbase += 4 * QP_NW) {
+        const int rem = ntiles - tbase;
+        const int ntj = (rem + QP_NW - 1) / QP_NW; /* same for every wavefront */
+        if (ntj <= 1) factor_panel_update<1>(L, Dg, n, ld, J, tbase);
+        else if (ntj == 2) factor_panel_update<2>(L, Dg, n, ld, J, tbase);
+        else if (ntj == 3) factor_panel_update<3>(L, Dg, n, ld, J, tbase);
+        else factor_panel_update<4>(L, Dg, n, ld, J, tbase);
+      }
     }
     __syncthreads();
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[4] += tq1 - tq0; tq0 = tq1; }
@@ -226,10 +276,10 @@ QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *
     if (wid == 0) {
       double p[QP_FNB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) p[c] = (lane < jb && c <= lane) ? L[(size_t)(J + c) * ld + (J + lane)] : 0.0;
+      for (int c = 0; c < NB; c++) p[c] = (lane < jb && c <= lane && !(dbgf & 16)) ? L[(size_t)(J + c) * ld + (J + lane)] : 1.0 + (c == lane);
 #pragma unroll
       for (int c = 0; c < NB; c++) {
-        if (c < jb) {
+        if (c < jb && !(dbgf & 8)) {
           if (lane < NB) F.colbuf[lane] = p[c]; /* un-normalised column c */
           QP_WAVE_SYNC();
           const double dc = F.colbuf[c];
@@ -244,7 +294,7 @@ QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *
 #pragma unroll
         for (int c = 0; c < NB; c++) {
           if (c < lane) { F.Ld[lane][c] = p[c]; L[(size_t)(J + c) * ld + (J + lane)] = p[c]; }
-          if (c == lane) { F.dv[c] = p[c]; Dg[J + c] = p[c]; }
+          if (c == lane) { F.dv[c] = 1.0 / p[c]; Dg[J + c] = p[c]; } /* reciprocal pivot for the panel rows */
         }
       }
     }
@@ -267,7 +317,7 @@ QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *
       }
 #pragma unroll
       for (int c = 0; c < NB; c++)
-        if (c < jb) L[(size_t)(J + c) * ld + i] = u[c] / F.dv[c];
+        if (c < jb) L[(size_t)(J + c) * ld + i] = u[c] * F.dv[c];
     }
     __syncthreads();
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
@@ -313,15 +363,13 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
       if (lane < jb) xs[J + lane] = v;
     }
     __syncthreads();
-    for (int i = J + jb + tid; i < n; i += QP_T) {
+    for (int i = J + jb + tid; i < n; i += QP_T) { /* 32 independent column loads in flight per row */
+      double lv[QP_SNB];
+#pragma unroll
+      for (int cc = 0; cc < NB; cc++) lv[cc] = L[(size_t)(J + ((cc < jb) ? cc : jb - 1)) * ld + i];
       double acc = xs[i];
-      for (int g = 0; g < jb; g += 8) { /* 8 independent column loads in flight per row */
-        double lv[8];
 #pragma unroll
-        for (int cc = 0; cc < 8; cc++) lv[cc] = (g + cc < jb) ? L[(size_t)(J + g + cc) * ld + i] : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 8; cc++) if (g + cc < jb) acc = QP_FMA(-lv[cc], xs[J + g + cc], acc);
-      }
+      for (int cc = 0; cc < NB; cc++) if (cc < jb) acc = QP_FMA(-lv[cc], xs[J + cc], acc);
       xs[i] = acc;
     }
   }
@@ -332,13 +380,33 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
   const int Jlast = ((n - 1) / NB) * NB;
   for (int J = Jlast; J >= 0; J -= NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
-    for (int c = wid; c < jb; c += QP_NW) {
-      double s = 0.0;
-      const double *col = L + (size_t)(J + c) * ld;
-#pragma unroll 4
-      for (int i = J + jb + lane; i < n; i += 64) s = QP_FMA(col[i], xs[i], s);
-      s = wave_sum(s);
-      if (lane == 0) T.part[c] = s;
+    { /* partial dots of the block's columns with x below the block: the NB/NW columns of this
+       * wavefront advance together, 4 x 64 rows per iteration => 16 independent loads per lane */
+      constexpr int CW = QP_SNB / QP_NW > 0 ? QP_SNB / QP_NW : 1;
+      double sacc[CW];
+#pragma unroll
+      for (int q = 0; q < CW; q++) sacc[q] = 0.0;
+      for (int i0 = J + jb; i0 < n; i0 += 256) {
+        double xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; xv[u] = (i < n) ? xs[i] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < CW; q++) {
+          const int c = wid + q * QP_NW;
+          const double *col = L + (size_t)(J + ((c < jb) ? c : jb - 1)) * ld;
+          double lv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; lv[u] = col[(i < n) ? i : n - 1]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) sacc[q] = QP_FMA(lv[u], xv[u], sacc[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CW; q++) {
+        const int c = wid + q * QP_NW;
+        const double sv = wave_sum(sacc[q]);
+        if (lane == 0 && c < jb) T.part[c] = sv;
+      }
     }
     for (int e = tid; e < jb * jb; e += QP_T) {
       const int c = e / jb, r = e % jb;
@@ -378,11 +446,12 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
  * then every thread applies the table to its rows below the block with L streamed from HBM.
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
-template <int K>
+template <int RPT, int K>
 struct UpdownLds {
   double Ld[QP_UNB][QP_UNB + 1];
   double Wd[QP_UNB][K + 1];
-  double cwg[QP_UNB][K][2]; /* (w_j, gamma) per column and rank, read as one 16-byte broadcast */
+  double cwg[QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
+  double stash[RPT][K][64]; /* wavefront 0 parks its running w here during the block recurrence */
   double Wt[K];
   double dd[QP_UNB];
 };
@@ -407,7 +476,8 @@ template <int RPT, int K>
 QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *cols, int n_up,
                       const int *cols_dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
   static_assert(K <= 16, "rank block must fit one DPP row");
-  UpdownLds<K> &U = *(UpdownLds<K> *)lds;
+  UpdownLds<RPT, K> &U = *(UpdownLds<RPT, K> *)lds;
+  static_assert(sizeof(UpdownLds<RPT, K>) <= 48 * 1024, "update scratch must fit the dynamic LDS");
   const int n = V.n, ld = V.ld, NB = QP_UNB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
@@ -460,13 +530,20 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
       if (jb < NB) for (int e = tid; e < (NB - jb) * K; e += QP_T) { U.cwg[jb + e / K][e % K][0] = 0.0; U.cwg[jb + e / K][e % K][1] = 0.0; }
       __syncthreads();
       if (wid == 0) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+          for (int r = 0; r < K; r++) U.stash[rr][r][lane] = w[rr][r];
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[lane][r] : 0.0;
+        double dreg = (lane < jb) ? U.dd[lane] : 1.0;          /* lane c holds the pivot of column c */
+        double lnext = (lane > 0 && lane < jb) ? U.Ld[lane][0] : 0.0;
 #pragma unroll
         for (int c1 = 0; c1 < NB; c1++) {
           if (c1 < jb) {
-            const double lcur = (lane > c1 && lane < jb) ? U.Ld[lane][c1] : 0.0; /* issued early, used after the scalars */
+            const double lcur = lnext;
+            if (c1 + 1 < NB) lnext = (lane > c1 + 1 && lane < jb) ? U.Ld[lane][c1 + 1] : 0.0; /* in flight during this column */
             if (lane == c1) {
 #pragma unroll
               for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
@@ -474,51 +551,48 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
             QP_WAVE_SYNC();
             /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
             const double wv = (lane < kk) ? U.Wt[lane] : 0.0;
-            const double d0 = U.dd[c1];
+            const double d0 = qp_readlane(dreg, c1);
             const double p = sg * wv * wv * ialpha;
             double incl = p;
-            if (!(V.dbg_flags & 4)) {
             if (K > 1) incl += qp_row_shr<1>(incl);
             if (K > 2) incl += qp_row_shr<2>(incl);
             if (K > 4) incl += qp_row_shr<4>(incl);
             if (K > 8) incl += qp_row_shr<8>(incl);
-            }
             const double excl = qp_row_shr<1>(incl);
             const double dnew = d0 + incl, dprev = d0 + excl;
-            const int dbgf = V.dbg_flags;
-            const double rdn = (dbgf & 1) ? dnew : 1.0 / dnew, rdp = (dbgf & 1) ? dprev : 1.0 / dprev;
+            const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
             const double gam = -sg * wv * ialpha * rdn;
             if (lane < K) { U.cwg[c1][lane][0] = -wv; U.cwg[c1][lane][1] = -gam; } /* stored negated: plain FMAs below */
             alpha = alpha * dnew * rdp;
             ialpha = ialpha * dprev * rdn;
-            if (lane == kk - 1) U.dd[c1] = dnew;
+            { /* final pivot of the column = value after the last rank */
+              const double dfin = qp_readlane(dnew, kk - 1);
+              if (lane == c1) dreg = dfin;
+            }
             QP_WAVE_SYNC();
-            /* rows of the block: lane = row; all K coefficient pairs are fetched first, then the
-             * l chain is one FMA per rank: l <- (1 + g w_j) l - g w_r ; w_r <- w_r - w_j l_r */
-            if (!(V.dbg_flags & 2)) {
+            /* rows of the block: lane = row.  Rows <= c1 are finished, their registers may be
+             * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
+            {
+              double cw[K], cg[K];
+#pragma unroll
+              for (int r = 0; r < K; r++) { cw[r] = U.cwg[c1][r][0]; cg[r] = U.cwg[c1][r][1]; }
               double l = lcur;
 #pragma unroll
-              for (int rb = 0; rb < K; rb += 8) {
-                double cw[8], cg[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[c1][rb + r][1] : 0.0; }
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                  if (rb + r < K) {
-                    const double ca = QP_FMA(cg[r], cw[r], 1.0);       /* 1 + gamma w_j */
-                    const double t = cg[r] * wrow[rb + r];             /* -gamma w_r */
-                    const double wn = QP_FMA(cw[r], l, wrow[rb + r]);  /* w_r - w_j l */
-                    l = QP_FMA(ca, l, t);
-                    if (lane > c1) wrow[rb + r] = wn;
-                  }
-                }
-                QP_SCHED_BARRIER();
+              for (int r = 0; r < K; r++) {
+                wrow[r] = QP_FMA(cw[r], l, wrow[r]);
+                l = QP_FMA(cg[r], wrow[r], l);
               }
               if (lane > c1 && lane < jb) U.Ld[lane][c1] = l;
             }
             QP_SCHED_BARRIER();
           }
         }
+        if (lane < jb) U.dd[lane] = dreg;
+        /* the running w of this wavefront's own rows comes back from the stash */
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+          for (int r = 0; r < K; r++) w[rr][r] = U.stash[rr][r][lane];
       }
       __syncthreads();
       if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[1] += tq1 - tq0; tq0 = tq1; }
@@ -528,17 +602,18 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
       }
       if (tid < jb) Dg[J + tid] = U.dd[tid];
       /* rows below the block: one column per iteration.  Branch-free body: rows that are not
-       * below the block read/write a private dummy cell (column stride 0), the column 8 ahead is
-       * prefetched into a register queue, and the (-w_j, -gamma) pairs are fetched half a column
-       * ahead of their use (two 8-rank buffers), so neither HBM nor LDS latency is exposed. */
+       * below the block read/write a private dummy cell (column stride 0); the column QD ahead is
+       * prefetched into a register queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts,
+       * four ranks at a time.  Register budget <= 128 VGPRs so that two workgroups share a CU. */
       bool any = false;
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) { const int i = tid + rr * QP_T; any = any || (i >= J + jb && i < n); }
       if (any) {
+        constexpr int QD = 4;
         double *dummy = Wst + (size_t)QPG_KMAX * n;
         double *rowp[RPT];
         size_t cstride[RPT];
-        double q[RPT][8];
+        double q[RPT][QD];
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
           const int i = tid + rr * QP_T;
@@ -546,50 +621,38 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
           rowp[rr] = ok ? (L + (size_t)J * ld + i) : (dummy + tid + rr * QP_T);
           cstride[rr] = ok ? (size_t)ld : 0;
 #pragma unroll
-          for (int cc = 0; cc < 8; cc++) q[rr][cc] = rowp[rr][(size_t)((cc < jb) ? cc : jb - 1) * cstride[rr]];
+          for (int cc = 0; cc < QD; cc++) q[rr][cc] = rowp[rr][(size_t)((cc < jb) ? cc : jb - 1) * cstride[rr]];
         }
-        constexpr int KH = (K + 1) / 2;
-        double ca[KH][2], cb[KH][2];
-#pragma unroll
-        for (int r = 0; r < KH; r++) { ca[r][0] = U.cwg[0][r][0]; ca[r][1] = U.cwg[0][r][1]; }
 #pragma unroll 1
         for (int c1 = 0; c1 < jb; c1++) {
           double l[RPT];
-          const int cpre = (c1 + 8 < jb) ? c1 + 8 : jb - 1;
+          const int cpre = (c1 + QD < jb) ? c1 + QD : jb - 1;
 #pragma unroll
           for (int rr = 0; rr < RPT; rr++) {
             l[rr] = q[rr][0];
 #pragma unroll
-            for (int cc = 0; cc < 7; cc++) q[rr][cc] = q[rr][cc + 1];
-            q[rr][7] = rowp[rr][(size_t)cpre * cstride[rr]];
+            for (int cc = 0; cc < QD - 1; cc++) q[rr][cc] = q[rr][cc + 1];
+            q[rr][QD - 1] = rowp[rr][(size_t)cpre * cstride[rr]];
           }
 #pragma unroll
-          for (int r = 0; r < K - KH; r++) { cb[r][0] = U.cwg[c1][KH + r][0]; cb[r][1] = U.cwg[c1][KH + r][1]; }
-          QP_SCHED_BARRIER();
+          for (int rb = 0; rb < K; rb += 4) {
+            double cf[4][2];
 #pragma unroll
-          for (int r = 0; r < KH; r++) {
+            for (int r = 0; r < 4; r++) { cf[r][0] = (rb + r < K) ? U.cwg[c1][rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? U.cwg[c1][rb + r][1] : 0.0; }
 #pragma unroll
-            for (int rr = 0; rr < RPT; rr++) {
-              w[rr][r] = QP_FMA(ca[r][0], l[rr], w[rr][r]);
-              l[rr] = QP_FMA(ca[r][1], w[rr][r], l[rr]);
+            for (int r = 0; r < 4; r++) {
+              if (rb + r < K) {
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr++) {
+                  w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
+                  l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
+                }
+              }
             }
-          }
-          QP_SCHED_BARRIER();
-          const int cn = (c1 + 1 < NB) ? c1 + 1 : c1;
-#pragma unroll
-          for (int r = 0; r < KH; r++) { ca[r][0] = U.cwg[cn][r][0]; ca[r][1] = U.cwg[cn][r][1]; }
-          QP_SCHED_BARRIER();
-#pragma unroll
-          for (int r = 0; r < K - KH; r++) {
-#pragma unroll
-            for (int rr = 0; rr < RPT; rr++) {
-              w[rr][KH + r] = QP_FMA(cb[r][0], l[rr], w[rr][KH + r]);
-              l[rr] = QP_FMA(cb[r][1], w[rr][KH + r], l[rr]);
-            }
+            QP_SCHED_BARRIER();
           }
 #pragma unroll
           for (int rr = 0; rr < RPT; rr++) rowp[rr][(size_t)c1 * cstride[rr]] = l[rr];
-          QP_SCHED_BARRIER();
         }
       }
       __syncthreads();

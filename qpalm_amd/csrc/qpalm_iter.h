@@ -239,7 +239,7 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
  * factorisation plumbing
  * =========================================================================================== */
 template <int RPT>
-QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds, tdbg); }
+QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds, tdbg, V.dbg_flags); }
 template <int RPT>
 QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *up, int n_up,
                     const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {

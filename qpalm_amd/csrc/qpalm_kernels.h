@@ -6,8 +6,14 @@
 
 #include "qpalm_device.h"
 
+/* two workgroups of 8 wavefronts per CU = 4 wavefronts per SIMD => at most 128 VGPRs */
 #ifndef QP_WAVES_PER_SIMD
-#define QP_WAVES_PER_SIMD 2
+#define QP_WAVES_PER_SIMD 4
+#endif
+#ifdef QPALM_EMU
+#define QP_OCCUPANCY
+#else
+#define QP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER_SIMD, QP_WAVES_PER_SIMD)))
 #endif
 #define QP_OP_MATVEC_A 1
 #define QP_OP_MATVEC_Q 2
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(QP_T) void k_warm_start(qpg_view V, int has_x, int 
 /* The persistent solver: workgroup `blockIdx.x` owns factor slot `blockIdx.x` and pulls QPs either
  * statically (b = blockIdx.x, resumable, needs B <= grid) or from an atomic work queue. */
 template <int RPT>
-__global__ __launch_bounds__(QP_T, QP_WAVES_PER_SIMD) void k_solve(qpg_view V, int budget, int dynamic) {
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_solve(qpg_view V, int budget, int dynamic) {
   __shared__ IterShared I;
   char *lds = QP_DYN_LDS();
   if (!dynamic) {

@@ -35,7 +35,10 @@ void run_block_impl(unsigned nthreads, unsigned bx, unsigned gx, size_t shmem, v
   B.waves.assign(nthreads / 64, Wave());
   for (auto &w : B.waves) { w.count = 0; w.gen = 0; }
   B.nthreads = nthreads; B.bar_count = 0; B.bar_gen = 0;
-  B.dyn_lds = (char *)calloc(shmem ? shmem : 16, 1);
+  const size_t kGuard = 4096;                 /* catches kernels that run past their dynamic LDS allocation */
+  const size_t lds_sz = shmem ? shmem : 16;
+  B.dyn_lds = (char *)calloc(lds_sz + kGuard, 1);
+  memset(B.dyn_lds + lds_sz, 0xA5, kGuard);
   g_tramp = tramp; g_arg = arg;
   g_blockIdx = emu_dim3(bx); g_blockDim = emu_dim3(nthreads); g_gridDim = emu_dim3(gx);
   for (unsigned t = 0; t < nthreads; t++) {
@@ -58,6 +61,8 @@ void run_block_impl(unsigned nthreads, unsigned bx, unsigned gx, size_t shmem, v
     }
     if (!alive) break;
   }
+  for (size_t k = 0; k < kGuard; k++)
+    if ((unsigned char)B.dyn_lds[lds_sz + k] != 0xA5) { fprintf(stderr, "hip_emu: dynamic LDS overrun at byte %zu (allocation %zu)\n", lds_sz + k, lds_sz); abort(); }
   free(B.dyn_lds); B.dyn_lds = nullptr;
 }
 }  // namespace emu
