@@ -537,57 +537,66 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[lane][r] : 0.0;
+        const long long tcol0 = QP_CLOCK();
         double dreg = (lane < jb) ? U.dd[lane] : 1.0;          /* lane c holds the pivot of column c */
         double lnext = (lane > 0 && lane < jb) ? U.Ld[lane][0] : 0.0;
+        /* Rolled on purpose: unrolled, the 32 lane masks and lane-derived LDS addresses become
+         * long-lived values that spill under the 128-VGPR cap, and every column then waits on
+         * ~5 dependent scratch loads (measured: 1830 clk/column vs ~900 for this form). */
+#pragma unroll 1
+        for (int c1 = 0; c1 < jb; c1++) {
+          const int ln = QP_FRESH_LANE(lane);
+          const double lcur = lnext;
+          lnext = (ln > c1 + 1 && ln < jb) ? U.Ld[ln][c1 + 1] : 0.0; /* in flight during this column (column NB is padding) */
+          if (ln == c1) {
 #pragma unroll
-        for (int c1 = 0; c1 < NB; c1++) {
-          if (c1 < jb) {
-            const double lcur = lnext;
-            if (c1 + 1 < NB) lnext = (lane > c1 + 1 && lane < jb) ? U.Ld[lane][c1 + 1] : 0.0; /* in flight during this column */
-            if (lane == c1) {
-#pragma unroll
-              for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
-            }
-            QP_WAVE_SYNC();
-            /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
-            const double wv = (lane < kk) ? U.Wt[lane] : 0.0;
-            const double d0 = qp_readlane(dreg, c1);
-            const double p = sg * wv * wv * ialpha;
-            double incl = p;
-            if (K > 1) incl += qp_row_shr<1>(incl);
-            if (K > 2) incl += qp_row_shr<2>(incl);
-            if (K > 4) incl += qp_row_shr<4>(incl);
-            if (K > 8) incl += qp_row_shr<8>(incl);
-            const double excl = qp_row_shr<1>(incl);
-            const double dnew = d0 + incl, dprev = d0 + excl;
-            const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
-            const double gam = -sg * wv * ialpha * rdn;
-            if (lane < K) { U.cwg[c1][lane][0] = -wv; U.cwg[c1][lane][1] = -gam; } /* stored negated: plain FMAs below */
-            alpha = alpha * dnew * rdp;
-            ialpha = ialpha * dprev * rdn;
-            { /* final pivot of the column = value after the last rank */
-              const double dfin = qp_readlane(dnew, kk - 1);
-              if (lane == c1) dreg = dfin;
-            }
-            QP_WAVE_SYNC();
-            /* rows of the block: lane = row.  Rows <= c1 are finished, their registers may be
-             * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
-            {
-              double cw[K], cg[K];
-#pragma unroll
-              for (int r = 0; r < K; r++) { cw[r] = U.cwg[c1][r][0]; cg[r] = U.cwg[c1][r][1]; }
-              double l = lcur;
-#pragma unroll
-              for (int r = 0; r < K; r++) {
-                wrow[r] = QP_FMA(cw[r], l, wrow[r]);
-                l = QP_FMA(cg[r], wrow[r], l);
-              }
-              if (lane > c1 && lane < jb) U.Ld[lane][c1] = l;
-            }
-            QP_SCHED_BARRIER();
+            for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
           }
+          QP_WAVE_SYNC();
+          /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
+          const double wv = (ln < kk) ? U.Wt[ln & (K - 1)] : 0.0;
+          const double d0 = qp_readlane(dreg, c1);
+          const double p = sg * wv * wv * ialpha;
+          double incl = p;
+          if (K > 1) incl += qp_row_shr<1>(incl);
+          if (K > 2) incl += qp_row_shr<2>(incl);
+          if (K > 4) incl += qp_row_shr<4>(incl);
+          if (K > 8) incl += qp_row_shr<8>(incl);
+          const double excl = qp_row_shr<1>(incl);
+          const double dnew = d0 + incl, dprev = d0 + excl;
+          const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
+          const double gam = -sg * wv * ialpha * rdn;
+          if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; } /* stored negated: plain FMAs below */
+          alpha = alpha * dnew * rdp;
+          ialpha = ialpha * dprev * rdn;
+          { /* final pivot of the column = value after the last rank */
+            const double dfin = qp_readlane(dnew, kk - 1);
+            if (ln == c1) dreg = dfin;
+          }
+          QP_WAVE_SYNC();
+          /* rows of the block: lane = row.  Rows <= c1 are finished, their registers may be
+           * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
+          {
+            double l = lcur;
+#pragma unroll
+            for (int rb = 0; rb < K; rb += 8) {
+              double cw[8], cg[8];
+#pragma unroll
+              for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[c1][rb + r][1] : 0.0; }
+#pragma unroll
+              for (int r = 0; r < 8; r++) {
+                if (rb + r < K) {
+                  wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
+                  l = QP_FMA(cg[r], wrow[rb + r], l);
+                }
+              }
+            }
+            if (ln > c1 && ln < jb) U.Ld[ln][c1] = l;
+          }
+          QP_SCHED_BARRIER();
         }
         if (lane < jb) U.dd[lane] = dreg;
+        if (lane == 0) tdbg[7] += QP_CLOCK() - tcol0;
         /* the running w of this wavefront's own rows comes back from the stash */
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)

@@ -37,6 +37,7 @@ typedef emu_double4 qp_double4;
 #define QP_CLOCK() ((long long)wall_clock64())
 #define QP_UNIFORM(x) (x)
 #define QP_OPAQUE(x) do { } while (0)
+#define QP_FRESH_LANE(lane) (lane)
 #else
 typedef double qp_double4 __attribute__((ext_vector_type(4)));
 #define QP_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -48,6 +49,14 @@ extern __shared__ __attribute__((aligned(16))) char qp_dyn_lds_[];
 #define QP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x) /* value is wave-uniform: keep it in an SGPR */
 /* stops LICM/CSE from keeping ~100 per-array addresses live across the whole iteration loop */
 #define QP_OPAQUE(x) asm volatile("" : "+s"(x))
+/* the lane id recomputed on the spot (2 VALU ops): inside latency-critical loops this keeps lane-derived
+ * LDS addresses and lane masks out of long-lived (= spilled, under the 128-VGPR cap) registers */
+static __device__ __forceinline__ int qp_fresh_lane_() {
+  int z = 0;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+}
+#define QP_FRESH_LANE(lane) qp_fresh_lane_()
 #endif
 
 /* ---- c_max / c_min / c_absval exactly as the reference's macros (include/global_opts.h) ---- */
