@@ -57,9 +57,9 @@ QPD double qp_rcp(double x) {
  * walked in ascending order (the order cholmod_aat accumulates in), lanes spread over the entries
  * of F(:,t) => conflict-free LDS adds, deterministic sums.
  * GERSH = true: no Q, full columns, returns max_j (C_jj + sum_{i!=j} |C_ij|)  (nonconvex.c:185-210).
+ * (GERSH is a run-time flag so that the kernel holds ONE copy of this loop nest.)
  * ------------------------------------------------------------------------------------------- */
-template <bool GERSH>
-QPN double form_schur(const qpg_view &V, int b, double *Lslot, bool with_AtSA, bool proximal, double gamma,
+QPN double form_schur(const qpg_view &V, int b, double *Lslot, const bool GERSH, bool with_AtSA, bool proximal, double gamma,
                       QpShared &S, char *lds) {
   const int n = V.n, ld = V.ld;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -503,7 +503,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
     double w[RPT][K];
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
-      const int i = tid + rr * QP_T;
+      const int i = tid * RPT + rr; /* adjacent rows per thread: finished rows retire whole wavefronts */
 #pragma unroll
       for (int r = 0; r < K; r++) w[rr][r] = (i < n && r < kk) ? Wst[(size_t)r * n + i] : 0.0;
     }
@@ -516,7 +516,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
       const int jb = (n - J < NB) ? (n - J) : NB;
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) {
-        const int i = tid + rr * QP_T;
+        const int i = tid * RPT + rr;
         if (i >= J && i < J + jb) {
 #pragma unroll
           for (int r = 0; r < K; r++) U.Wd[i - J][r] = w[rr][r];
@@ -616,7 +616,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
        * four ranks at a time.  Register budget <= 128 VGPRs so that two workgroups share a CU. */
       bool any = false;
 #pragma unroll
-      for (int rr = 0; rr < RPT; rr++) { const int i = tid + rr * QP_T; any = any || (i >= J + jb && i < n); }
+      for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= J + jb && i < n); }
       if (any) {
         constexpr int QD = 4;
         double *dummy = Wst + (size_t)QPG_KMAX * n;
@@ -625,7 +625,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
         double q[RPT][QD];
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
-          const int i = tid + rr * QP_T;
+          const int i = tid * RPT + rr;
           const bool ok = (i >= J + jb && i < n);
           rowp[rr] = ok ? (L + (size_t)J * ld + i) : (dummy + tid + rr * QP_T);
           cstride[rr] = ok ? (size_t)ld : 0;

@@ -249,9 +249,10 @@ QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst
 /* =============================================================================================
  * update_sigma (iteration.c:86-145) + ldlupdate_sigma_changed (solver_interface.c:443-503)
  * =========================================================================================== */
-template <int RPT>
-QPN void dev_update_sigma(const qpg_view &V, const QpArrays &a, int b, IterShared &I, double *L, double *Dg,
-                          double *Wst, char *lds) {
+/* Part 1: new sigma, rescaled At_sqrt_sigma, list of changed rows (in a.enter()).  Returns the number
+ * of rank-1 updates ldlupdate_sigma_changed has to apply (0: nothing to do or a refactorisation was
+ * requested); the update itself runs at dev_solve's single linear-algebra site, then part 2. */
+QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I) {
   const qpg_settings &st = *V.settings;
   const int n = a.n, m = a.m, tid = threadIdx.x;
   double vm[1] = {0.0}, vs[1] = {0.0};
@@ -289,6 +290,7 @@ QPN void dev_update_sigma(const qpg_view &V, const QpArrays &a, int b, IterShare
   if (tid == 0) { I.s.nb_sigma_changed = nchg; I.s.n_sigma_updates++; }
   __syncthreads();
   const double thr = qmin(st.max_rank_update_fraction * (double)(n + m), 0.25 * (double)st.max_rank_update);
+  int nupd = 0;
   if ((st.proximal && I.s.gamma < st.gamma_max) || ((double)nchg > thr)) {
     if (tid == 0) I.s.reset_newton = 1;
   } else if (nchg == 0) {
@@ -302,15 +304,20 @@ QPN void dev_update_sigma(const qpg_view &V, const QpArrays &a, int b, IterShare
       a.At_scale()[row] = s;
       for (int e = a.Atp()[row]; e < a.Atp()[row + 1]; e++) a.Atss()[e] *= s;
     }
-    __syncthreads();
-    dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds, I.s.ticks_dbg);
-    for (int k = tid; k < m; k += QP_T) {
-      const double s = 1.0 / a.At_scale()[k];
-      a.At_scale()[k] = s;
-      if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s;
-    }
-    if (tid == 0) { I.s.n_rank1 += nchg; }
+    nupd = nchg;
   }
+  __syncthreads();
+  return nupd;
+}
+/* Part 2, after the rank updates: At_sqrt_sigma back to sqrt(sigma) scaling (solver_interface.c:498-502) */
+QPN void dev_update_sigma_post(const QpArrays &a, IterShared &I, int nchg) {
+  const int m = a.m, tid = threadIdx.x;
+  for (int k = tid; k < m; k += QP_T) {
+    const double s = 1.0 / a.At_scale()[k];
+    a.At_scale()[k] = s;
+    if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s;
+  }
+  if (tid == 0) { I.s.n_rank1 += nchg; }
   __syncthreads();
 }
 
@@ -346,13 +353,13 @@ QPN void dev_active_sets(const QpArrays &a, IterShared &I) {
   __syncthreads();
 }
 
-/* boost_gamma (iteration.c:158-211) */
-QPN void dev_boost_gamma(const qpg_view &V, const QpArrays &a, int b, IterShared &I, double *L, char *lds) {
+/* boost_gamma (iteration.c:158-211); `ub` = Gershgorin bound of A' Sigma_active A, formed at dev_solve's
+ * single linear-algebra site when there are active constraints */
+QPN void dev_boost_gamma_apply(const qpg_view &V, const QpArrays &a, IterShared &I, double ub) {
   const qpg_settings &st = *V.settings;
   const double prev = I.s.gamma;
   double g;
   if (I.s.nb_active) {
-    const double ub = form_schur<true>(V, b, L, true, false, 0.0, I.S, lds);
     g = qmax(st.gamma_max, 1e14 / ub);
     if (threadIdx.x == 0) I.s.gamma_maxed = 1;
   } else g = 1e12;
@@ -678,42 +685,41 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       if (tid == 0) { I.s.done = 1; I.s.initialized = 0; I.s.in_solve = 0; I.s.last_kind = QP_KIND_TERMINATED; }
       break;
     }
-    if (kind == QP_KIND_OUTER) {
+    /* At most ONE linear-algebra operation per iteration, so form_schur / factor / update each have a
+     * single call site (one copy of those loop nests in the kernel):
+     *   1 refactor Q + A' Sigma_act A   2 update entering / downdate leaving   3 factor Q (+ I/gamma)
+     *   4 update for changed sigma       5 Gershgorin bound for boost_gamma      6 boost_gamma without bound */
+    int la = 0, n_sig = 0, action = 0, nchange = 0;
+    if (kind == QP_KIND_OUTER || kind == QP_KIND_FORCED) { /* qpalm.c:585-660 */
       if (tid == 0) I.s.no_change = 0;
       __syncthreads();
-      if (I.s.iter_out > 0 && I.s.pri_res_norm > I.s.eps_pri) dev_update_sigma<RPT>(V, a, b, I, L, Dg, Wst, lds);
-      for (int i = tid; i < m; i += QP_T) a.y()[i] = a.yh()[i];
-      for (int j = tid; j < n; j += QP_T) a.Aty()[j] = a.Atyh()[j];
-      __syncthreads();
-      if (tid == 0) {
-        I.s.eps_abs_in = qmax(st.eps_abs, st.rho * I.s.eps_abs_in);
-        I.s.eps_rel_in = qmax(st.eps_rel, st.rho * I.s.eps_rel_in);
-      }
-      __syncthreads();
-      if (prox) { /* qpalm.c:612-630 (convex) */
-        if (!I.s.gamma_maxed && I.s.iter_out > 0 && I.s.nb_enter == 0 && I.s.nb_leave == 0 && I.s.pri_res_norm < I.s.eps_pri) {
-          for (int i = tid; i < m; i += QP_T) { const double t = a.y()[i] / a.sigma()[i]; a.Axys()[i] = a.Axv()[i] + 1 * t; } /* B3 */
-          __syncthreads();
-          dev_active_sets(a, I);
-          if (I.s.nb_enter == 0 && I.s.nb_leave == 0) dev_boost_gamma(V, a, b, I, L, lds);
-          else dev_update_gamma(V, a, I);
-        } else dev_update_gamma(V, a, I);
-        for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
-      }
-      for (int i = tid; i < m; i += QP_T) a.pri_res_in()[i] = a.pri_res()[i];
-      __syncthreads();
-      if (tid == 0) { I.s.iter_out++; I.s.prev_iter = I.s.iter; I.s.last_kind = QP_KIND_OUTER; I.s.last_fact = 0; }
-    } else if (kind == QP_KIND_FORCED) { /* qpalm.c:647-660 */
-      if (tid == 0) I.s.no_change = 0;
-      __syncthreads();
-      if (I.s.iter_out > 0 && I.s.pri_res_norm > I.s.eps_pri) dev_update_sigma<RPT>(V, a, b, I, L, Dg, Wst, lds);
-      if (prox) {
+      if (I.s.iter_out > 0 && I.s.pri_res_norm > I.s.eps_pri) { n_sig = dev_update_sigma_pre(V, a, I); if (n_sig > 0) la = 4; }
+      if (kind == QP_KIND_OUTER) {
+        for (int i = tid; i < m; i += QP_T) a.y()[i] = a.yh()[i];
+        for (int j = tid; j < n; j += QP_T) a.Aty()[j] = a.Atyh()[j];
+        __syncthreads();
+        if (tid == 0) {
+          I.s.eps_abs_in = qmax(st.eps_abs, st.rho * I.s.eps_abs_in);
+          I.s.eps_rel_in = qmax(st.eps_rel, st.rho * I.s.eps_rel_in);
+        }
+        __syncthreads();
+        if (prox) { /* qpalm.c:612-630 (convex) */
+          if (!I.s.gamma_maxed && I.s.iter_out > 0 && I.s.nb_enter == 0 && I.s.nb_leave == 0 && I.s.pri_res_norm < I.s.eps_pri) {
+            for (int i = tid; i < m; i += QP_T) { const double t = a.y()[i] / a.sigma()[i]; a.Axys()[i] = a.Axv()[i] + 1 * t; } /* B3 */
+            __syncthreads();
+            dev_active_sets(a, I);
+            if (I.s.nb_enter == 0 && I.s.nb_leave == 0) la = I.s.nb_active ? 5 : 6; /* boost_gamma */
+            else dev_update_gamma(V, a, I);
+          } else dev_update_gamma(V, a, I);
+          for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
+        }
+      } else if (prox) { /* qpalm.c:647-660 */
         dev_update_gamma(V, a, I);
         if (!st.nonconvex) for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
       }
       for (int i = tid; i < m; i += QP_T) a.pri_res_in()[i] = a.pri_res()[i];
       __syncthreads();
-      if (tid == 0) { I.s.iter_out++; I.s.prev_iter = I.s.iter; I.s.last_kind = QP_KIND_FORCED; I.s.last_fact = 0; }
+      if (tid == 0) { I.s.iter_out++; I.s.prev_iter = I.s.iter; I.s.last_kind = kind; I.s.last_fact = 0; }
     } else { /* Newton step, qpalm.c:662-668 -> update_primal_iterate (iteration.c:213-229) */
       if (tid == 0) {
         if (I.s.nb_enter + I.s.nb_leave) I.s.no_change = 0; else I.s.no_change++;
@@ -722,28 +728,32 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       __syncthreads();
       dev_active_sets(a, I);
       /* newton_set_direction, SCHUR branch (newton.c:96-113) */
-      const int nchange = I.s.nb_enter + I.s.nb_leave;
+      nchange = I.s.nb_enter + I.s.nb_leave;
       const double thr = qmin(st.max_rank_update_fraction * (double)(n + m), (double)st.max_rank_update);
-      int action;
       if ((I.s.reset_newton && I.s.nb_active) || ((double)nchange > thr) ||
           (V.update_rank_threshold >= 0 && I.s.nb_active && nchange > V.update_rank_threshold)) action = 1;
       else if (I.s.nb_active) action = nchange ? 2 : 0;
       else action = 3;
-      QP_OPAQUE(a.b);
-      const long long t0 = QP_CLOCK();
-      if (action == 1) {
-        form_schur<false>(V, b, L, true, prox != 0, gam, I.S, lds);
-        if (tid == 0) I.s.ticks_dbg[3] += QP_CLOCK() - t0;
-        dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
-      } else if (action == 3) {
-        form_schur<false>(V, b, L, false, prox != 0, gam, I.S, lds);
-        if (tid == 0) I.s.ticks_dbg[3] += QP_CLOCK() - t0;
-        dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
-      } else if (action == 2) {
-        dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), I.s.nb_leave, I.S, lds, I.s.ticks_dbg);
-      }
-      const long long t1 = QP_CLOCK();
-      QP_OPAQUE(a.b);
+      la = action;
+    }
+    QP_OPAQUE(a.b);
+    const long long t0 = QP_CLOCK();
+    double gersh_ub = 0.0;
+    if (la == 1 || la == 3 || la == 5) {
+      gersh_ub = form_schur(V, b, L, la == 5, la != 3, (la != 5) && (prox != 0), gam, I.S, lds);
+      if (tid == 0) I.s.ticks_dbg[3] += QP_CLOCK() - t0;
+      if (la != 5) dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
+    } else if (la == 2 || la == 4) {
+      const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
+      dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg);
+    }
+    const long long t1 = QP_CLOCK();
+    QP_OPAQUE(a.b);
+    if (la == 4) {
+      dev_update_sigma_post(a, I, n_sig);
+      if (tid == 0) { I.s.n_sweeps += (n_sig + 15) / 16; I.s.ticks_update += t1 - t0; }
+    } else if (la >= 5) dev_boost_gamma_apply(V, a, I, gersh_ub);
+    if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
       for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
       __syncthreads();

@@ -88,17 +88,18 @@ template <int RPT>
 __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_solve(qpg_view V, int budget, int dynamic) {
   __shared__ IterShared I;
   char *lds = QP_DYN_LDS();
-  if (!dynamic) {
-    for (int b = blockIdx.x; b < V.B; b += gridDim.x) dev_solve<RPT>(V, b, blockIdx.x, budget, I, lds);
-  } else {
-    while (true) {
+  /* one call site of dev_solve (= one copy of the iteration loop in the kernel): static round-robin
+   * or the atomic work queue only differ in how the next QP index is obtained */
+  int b = blockIdx.x - gridDim.x;
+  while (true) {
+    if (dynamic) {
       __syncthreads();
       if (threadIdx.x == 0) I.S.ibc[0] = atomicAdd(V.queue, 1);
       __syncthreads();
-      const int b = QP_UNIFORM(I.S.ibc[0]);
-      if (b >= V.B) break;
-      dev_solve<RPT>(V, b, blockIdx.x, budget, I, lds);
-    }
+      b = QP_UNIFORM(I.S.ibc[0]);
+    } else b += gridDim.x;
+    if (b >= V.B) break;
+    dev_solve<RPT>(V, b, blockIdx.x, budget, I, lds);
   }
 }
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
     case QP_OP_MATVEC_Q: spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
     case QP_OP_MATTVEC_A: spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
     case QP_OP_LDLCHOL:
-      form_schur<false>(V, b, L, false, st.proximal != 0, I.s.gamma, I.S, lds);
+      form_schur(V, b, L, false, false, st.proximal != 0, I.s.gamma, I.S, lds);
       dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_FACTOR_LOADED: /* the host wrote a symmetric matrix (lower triangle) into the slot */
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
       dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_LDLCHOL_QATSA:
-      form_schur<false>(V, b, L, true, st.proximal != 0, I.s.gamma, I.S, lds);
+      form_schur(V, b, L, false, true, st.proximal != 0, I.s.gamma, I.S, lds);
       dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_UPDATE_ENTER: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), 0, I.S, lds, I.s.ticks_dbg); break;
