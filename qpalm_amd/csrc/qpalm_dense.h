@@ -439,21 +439,29 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
  * Per column j and rank r (Davis & Hager method C1), with alpha_r carried along the columns:
  *     p = s w_j^2/alpha ; d_new = d + p ; gamma = -s w_j/(alpha d_new) ; alpha <- alpha d_new/d
  *     for i > j:  w_i -= w_j l_ij ;  l_ij -= gamma w_i
- * Thread t owns rows t, t+QP_T, ... and keeps their K running w values in registers for the whole
- * sweep.  Per block column of 32: wavefront 0 runs the recurrence on the block's own rows (lane =
- * row, everything in registers; rank-indexed scalars are produced with lane = rank, one reciprocal
- * per column on the critical path, DPP row scans) and publishes the (w_j, gamma) table through LDS;
- * then every thread applies the table to its rows below the block with L streamed from HBM.
+ * Thread t owns rows RPT t .. RPT t + RPT-1 and keeps their K running w values in registers for the
+ * whole sweep.  Per block column of 32 the recurrence on the block's own rows is a serial chain (one
+ * wavefront: lane = row, everything in registers; rank-indexed scalars are produced with lane = rank,
+ * one reciprocal per column on the critical path, DPP row scans); it publishes the (w_j, gamma) table
+ * through LDS and every thread applies the table to its rows below the block with L streamed from HBM.
+ *
+ * Look-ahead: wavefront 0 is the panel wave and runs ONE BLOCK AHEAD of the others.  In phase s
+ *     wavefront 0 : applies table s-1 to the 32 rows of block s (handed over by their owners), runs the
+ *                   recurrence of block s -> table s, writes the diagonal block back;
+ *     the others  : apply table s-1 to their rows below block s, hand the rows of block s+1 over,
+ *                   fetch diagonal block s+1 into LDS;
+ * one barrier per phase; tables, hand-over buffers and diagonal blocks are double buffered.  The
+ * arithmetic per entry is the same sequence of FMAs as without look-ahead.
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
 template <int RPT, int K>
-struct UpdownLds {
-  double Ld[QP_UNB][QP_UNB + 1];
-  double Wd[QP_UNB][K + 1];
-  double cwg[QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
-  double stash[RPT][K][64]; /* wavefront 0 parks its running w here during the block recurrence */
+struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
+  double Ld[2][QP_UNB][QP_UNB + 1];
+  double Wd[2][QP_UNB][K + 1]; /* running w of the rows of a block, handed from their owners to wavefront 0 */
+  double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
+  double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
-  double dd[QP_UNB];
+  double dd[2][QP_UNB];
 };
 
 #ifdef QPALM_EMU
@@ -477,7 +485,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
                       const int *cols_dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
   static_assert(K <= 16, "rank block must fit one DPP row");
   UpdownLds<RPT, K> &U = *(UpdownLds<RPT, K> *)lds;
-  static_assert(sizeof(UpdownLds<RPT, K>) <= 48 * 1024, "update scratch must fit the dynamic LDS");
+  static_assert(sizeof(UpdownLds<RPT, K>) <= 64 * 1024, "update scratch must fit the dynamic LDS (lds_bytes >= 64 KB)");
   const int n = V.n, ld = V.ld, NB = QP_UNB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
@@ -512,34 +520,84 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
     const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
     const int J0 = (jmin / NB) * NB;
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1; }
-    for (int J = J0; J < n; J += NB) {
-      const int jb = (n - J < NB) ? (n - J) : NB;
+    const int nblk = (n - J0 + NB - 1) / NB;
+    double *dummy = Wst + (size_t)QPG_KMAX * n;
+    /* prologue: rows of block 0 to the hand-over buffer, diagonal block 0 to LDS */
+    {
+      const int jb0 = (n - J0 < NB) ? (n - J0) : NB;
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) {
         const int i = tid * RPT + rr;
-        if (i >= J && i < J + jb) {
+        if (i >= J0 && i < J0 + jb0) {
 #pragma unroll
-          for (int r = 0; r < K; r++) U.Wd[i - J][r] = w[rr][r];
+          for (int r = 0; r < K; r++) U.Wd[0][i - J0][r] = w[rr][r];
         }
       }
-      for (int e = tid; e < jb * jb; e += QP_T) {
-        const int c1 = e / jb, c = e % jb;
-        if (c > c1) U.Ld[c][c1] = L[(size_t)(J + c1) * ld + (J + c)];
+      for (int e = tid; e < jb0 * jb0; e += QP_T) {
+        const int c1 = e / jb0, c = e % jb0;
+        if (c > c1) U.Ld[0][c][c1] = L[(size_t)(J0 + c1) * ld + (J0 + c)];
       }
-      if (tid < jb) U.dd[tid] = Dg[J + tid];
-      if (jb < NB) for (int e = tid; e < (NB - jb) * K; e += QP_T) { U.cwg[jb + e / K][e % K][0] = 0.0; U.cwg[jb + e / K][e % K][1] = 0.0; }
-      __syncthreads();
+      if (tid < jb0) U.dd[0][tid] = Dg[J0 + tid];
       if (wid == 0) {
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
           for (int r = 0; r < K; r++) U.stash[rr][r][lane] = w[rr][r];
+      }
+    }
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1; }
+    __syncthreads();
+    for (int s = 0; s < nblk; s++) {
+      const int J = J0 + s * NB, Jp = J - NB, Jn = J + NB;
+      const int jb = (n - J < NB) ? (n - J) : NB;
+      const int jbn = (n - Jn < NB) ? ((n - Jn > 0) ? (n - Jn) : 0) : NB; /* 0 when block s is the last one */
+      const int cur = s & 1, prv = cur ^ 1;
+      const bool own_live0 = (64 * RPT - 1 >= Jn); /* wavefront 0 still owns rows below block s */
+      if (wid == 0) {
+        /* ===== panel wave ===================================================================== */
+        const long long tp0 = QP_CLOCK();
         double wrow[K];
 #pragma unroll
-        for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[lane][r] : 0.0;
-        const long long tcol0 = QP_CLOCK();
-        double dreg = (lane < jb) ? U.dd[lane] : 1.0;          /* lane c holds the pivot of column c */
-        double lnext = (lane > 0 && lane < jb) ? U.Ld[lane][0] : 0.0;
+        for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[cur][lane][r] : 0.0;
+        if (s > 0) {
+          /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows */
+          constexpr int QD = 4;
+          double *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
+          const size_t cstride = (lane < jb) ? (size_t)ld : 0;
+          double q[QD];
+#pragma unroll
+          for (int cc = 0; cc < QD; cc++) q[cc] = rowp[(size_t)cc * cstride];
+          /* unrolled by the queue depth: slot u of the queue is a fixed register, so the load
+           * issued QD columns ago is the only one waited for (rotating the queue through register
+           * moves would make every column wait for the newest load) */
+#pragma unroll 1
+          for (int c0 = 0; c0 < NB; c0 += QD) {
+#pragma unroll
+            for (int u = 0; u < QD; u++) {
+              const int c1 = c0 + u;
+              double l = q[u];
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+              q[u] = rowp[(size_t)cpre * cstride];
+#pragma unroll
+              for (int rb = 0; rb < K; rb += 8) {
+                double cw[8], cg[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                  if (rb + r < K) {
+                    wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
+                    l = QP_FMA(cg[r], wrow[rb + r], l);
+                  }
+                }
+              }
+              rowp[(size_t)c1 * cstride] = l;
+              QP_SCHED_BARRIER();
+            }
+          }
+        }
+        double dreg = (lane < jb) ? U.dd[cur][lane] : 1.0;          /* lane c holds the pivot of column c */
+        double lnext = (lane > 0 && lane < jb) ? U.Ld[cur][lane][0] : 0.0;
         /* Rolled on purpose: unrolled, the 32 lane masks and lane-derived LDS addresses become
          * long-lived values that spill under the 128-VGPR cap, and every column then waits on
          * ~5 dependent scratch loads (measured: 1830 clk/column vs ~900 for this form). */
@@ -547,7 +605,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
         for (int c1 = 0; c1 < jb; c1++) {
           const int ln = QP_FRESH_LANE(lane);
           const double lcur = lnext;
-          lnext = (ln > c1 + 1 && ln < jb) ? U.Ld[ln][c1 + 1] : 0.0; /* in flight during this column (column NB is padding) */
+          lnext = (ln > c1 + 1 && ln < jb) ? U.Ld[cur][ln][c1 + 1] : 0.0; /* in flight during this column (column NB is padding) */
           if (ln == c1) {
 #pragma unroll
             for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
@@ -566,7 +624,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
           const double dnew = d0 + incl, dprev = d0 + excl;
           const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
           const double gam = -sg * wv * ialpha * rdn;
-          if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; } /* stored negated: plain FMAs below */
+          if (ln < K) { U.cwg[cur][c1][ln][0] = -wv; U.cwg[cur][c1][ln][1] = -gam; } /* stored negated: plain FMAs below */
           alpha = alpha * dnew * rdp;
           ialpha = ialpha * dprev * rdn;
           { /* final pivot of the column = value after the last rank */
@@ -582,7 +640,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
             for (int rb = 0; rb < K; rb += 8) {
               double cw[8], cg[8];
 #pragma unroll
-              for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[c1][rb + r][1] : 0.0; }
+              for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][1] : 0.0; }
 #pragma unroll
               for (int r = 0; r < 8; r++) {
                 if (rb + r < K) {
@@ -591,82 +649,108 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
                 }
               }
             }
-            if (ln > c1 && ln < jb) U.Ld[ln][c1] = l;
+            if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;
           }
           QP_SCHED_BARRIER();
         }
-        if (lane < jb) U.dd[lane] = dreg;
-        if (lane == 0) tdbg[7] += QP_CLOCK() - tcol0;
-        /* the running w of this wavefront's own rows comes back from the stash */
+        /* diagonal block and pivots back to HBM (each lane re-reads what it wrote itself) */
+        if (lane < jb) Dg[J + lane] = dreg;
+#pragma unroll 1
+        for (int c = 0; c < jb; c++)
+          if (lane > c && lane < jb) L[(size_t)(J + c) * ld + (J + lane)] = U.Ld[cur][lane][c];
+        /* back to being an ordinary owner: the running w of this wavefront's own rows */
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
-          for (int r = 0; r < K; r++) w[rr][r] = U.stash[rr][r][lane];
+          for (int r = 0; r < K; r++) w[rr][r] = own_live0 ? U.stash[rr][r][lane] : 0.0;
+        if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
       }
-      __syncthreads();
-      if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[1] += tq1 - tq0; tq0 = tq1; }
-      for (int e = tid; e < jb * jb; e += QP_T) {
-        const int c1 = e / jb, c = e % jb;
-        if (c > c1) L[(size_t)(J + c1) * ld + (J + c)] = U.Ld[c][c1];
-      }
-      if (tid < jb) Dg[J + tid] = U.dd[tid];
-      /* rows below the block: one column per iteration.  Branch-free body: rows that are not
-       * below the block read/write a private dummy cell (column stride 0); the column QD ahead is
-       * prefetched into a register queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts,
-       * four ranks at a time.  Register budget <= 128 VGPRs so that two workgroups share a CU. */
-      bool any = false;
+      if (wid != 0 || own_live0) {
+        /* ===== owners: table s-1 on the rows below block s ======================================= */
+        const long long tt0 = QP_CLOCK();
+        bool any = false;
 #pragma unroll
-      for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= J + jb && i < n); }
-      if (any) {
-        constexpr int QD = 4;
-        double *dummy = Wst + (size_t)QPG_KMAX * n;
-        double *rowp[RPT];
-        size_t cstride[RPT];
-        double q[RPT][QD];
+        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jn && i < n); }
+        if (s > 0 && any) {
+          /* One column per iteration.  Branch-free body: rows that are not below the block read/write
+           * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
+           * queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four ranks at a time.
+           * Register budget <= 128 VGPRs so that two workgroups share a CU. */
+          constexpr int QD = 4;
+          double *rowp[RPT];
+          size_t cstride[RPT];
+          double q[RPT][QD];
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) {
+            const int i = tid * RPT + rr;
+            const bool ok = (i >= Jn && i < n);
+            rowp[rr] = ok ? (L + (size_t)Jp * ld + i) : (dummy + tid + rr * QP_T);
+            cstride[rr] = ok ? (size_t)ld : 0;
+#pragma unroll
+            for (int cc = 0; cc < QD; cc++) q[rr][cc] = rowp[rr][(size_t)cc * cstride[rr]];
+          }
+#pragma unroll 1
+          for (int c0 = 0; c0 < NB; c0 += QD) {
+#pragma unroll
+            for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
+              const int c1 = c0 + u;
+              double l[RPT];
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+#pragma unroll
+              for (int rr = 0; rr < RPT; rr++) {
+                l[rr] = q[rr][u];
+                q[rr][u] = rowp[rr][(size_t)cpre * cstride[rr]];
+              }
+#pragma unroll
+              for (int rb = 0; rb < K; rb += 4) {
+                double cf[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { cf[r][0] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                  if (rb + r < K) {
+#pragma unroll
+                    for (int rr = 0; rr < RPT; rr++) {
+                      w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
+                      l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
+                    }
+                  }
+                }
+                QP_SCHED_BARRIER();
+              }
+#pragma unroll
+              for (int rr = 0; rr < RPT; rr++) rowp[rr][(size_t)c1 * cstride[rr]] = l[rr];
+            }
+          }
+        }
+        /* rows of block s+1 to the hand-over buffer of the next phase */
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
           const int i = tid * RPT + rr;
-          const bool ok = (i >= J + jb && i < n);
-          rowp[rr] = ok ? (L + (size_t)J * ld + i) : (dummy + tid + rr * QP_T);
-          cstride[rr] = ok ? (size_t)ld : 0;
+          if (i >= Jn && i < Jn + jbn) {
 #pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[rr][cc] = rowp[rr][(size_t)((cc < jb) ? cc : jb - 1) * cstride[rr]];
-        }
-#pragma unroll 1
-        for (int c1 = 0; c1 < jb; c1++) {
-          double l[RPT];
-          const int cpre = (c1 + QD < jb) ? c1 + QD : jb - 1;
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) {
-            l[rr] = q[rr][0];
-#pragma unroll
-            for (int cc = 0; cc < QD - 1; cc++) q[rr][cc] = q[rr][cc + 1];
-            q[rr][QD - 1] = rowp[rr][(size_t)cpre * cstride[rr]];
+            for (int r = 0; r < K; r++) U.Wd[prv][i - Jn][r] = w[rr][r];
           }
-#pragma unroll
-          for (int rb = 0; rb < K; rb += 4) {
-            double cf[4][2];
-#pragma unroll
-            for (int r = 0; r < 4; r++) { cf[r][0] = (rb + r < K) ? U.cwg[c1][rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? U.cwg[c1][rb + r][1] : 0.0; }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              if (rb + r < K) {
-#pragma unroll
-                for (int rr = 0; rr < RPT; rr++) {
-                  w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
-                  l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
-                }
-              }
-            }
-            QP_SCHED_BARRIER();
-          }
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) rowp[rr][(size_t)c1 * cstride[rr]] = l[rr];
         }
+        if (wid == 0) {
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+            for (int r = 0; r < K; r++) U.stash[rr][r][lane] = w[rr][r];
+        }
+        if (tid == QP_T - 64) tdbg[2] += QP_CLOCK() - tt0; /* the last wavefront's rows live longest */
+      }
+      if (wid != 0 || QP_NW == 1) { /* diagonal block s+1 for the next phase */
+        const int t0 = (QP_NW == 1) ? tid : tid - 64, nt = (QP_NW == 1) ? QP_T : QP_T - 64;
+        for (int e = t0; e < jbn * jbn; e += nt) {
+          const int c1 = e / jbn, c = e % jbn;
+          if (c > c1) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
+        }
+        if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
       }
       __syncthreads();
-      if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[2] += tq1 - tq0; tq0 = tq1; }
     }
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[7] += tq1 - tq0; tq0 = tq1; }
   }
   __syncthreads();
 }
