@@ -173,7 +173,7 @@ def main():
     kms = float(np.mean(kernel_ms))
     achieved = tot_bytes / (kms * 1e-3) / 1e9
     phase = {k: float(np.mean([getattr(s, k) for s in stats])) for k in ("ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")}
-    phase["dbg"] = [float(np.mean([s.ms_dbg[k] for s in stats])) for k in range(8)]
+    phase["dbg"] = [float(np.mean([s.ms_dbg[k] for s in stats])) for k in range(16)]
 
     out = None
     if rank == 0:

@@ -107,7 +107,9 @@ typedef struct {
   qpg_int nb_active, nb_enter, nb_leave, last_kind, last_fact;
   qpg_float gamma, tau, eta, beta, eps_pri, eps_dua, eps_dua_in, sc_c;
   qpg_float ms_total, ms_factor, ms_update, ms_solve, ms_linesearch;
-  qpg_float ms_dbg[8]; /* update: 0 staging, 1 block-row recurrence, 2 trailing rows; factor: 3 form, 4 panel gemm, 5 block, 6 panel solve; 7 residual phase */
+  qpg_float ms_dbg[16]; /* update: 0 staging, 1 panel wave busy, 2 last trailing wave busy, 7 sweep phases (wall);
+                           factor: 3 form, 4 panel gemm, 5 block, 6 panel solve;
+                           solve: 8 forward block, 9 forward rows below, 10 backward dots, 11 backward block; 12 SpMV+residuals */
 } QPGStats;
 
 typedef struct qpg_ctx qpg_ctx;

@@ -168,9 +168,11 @@ QPN double form_schur(const qpg_view &V, int b, double *Lslot, const bool GERSH,
  *  (3) rows below the block are finished one row per thread with the block's L, D from LDS.
  * ------------------------------------------------------------------------------------------- */
 #define QP_FNB 32
+#define QP_FNT 2 /* row tiles per wavefront and pass of the panel update: 2 keeps accumulators + two fragment stages under 128 VGPRs */
 struct FactorLds {
   double Ld[QP_FNB][QP_FNB + 1];
   double dv[QP_FNB];
+  double dg[QP_FNB];
   double colbuf[QP_FNB];
 };
 
@@ -258,47 +260,55 @@ QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *
   long long tq0 = QP_CLOCK();
   for (int J = 0; J < n; J += NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
-    /* ---- (1) panel update on the matrix cores: passes of at most 4 row tiles per wavefront ---- */
+    /* ---- (1) panel update on the matrix cores: passes of at most QP_FNT row tiles per wavefront ---- */
     {
       const int ntiles = (n - J + 15) / 16;
-      for (int tbase = 0; tbase < ntiles; tbase += 4 * QP_NW) {
+      for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW) {
         const int rem = ntiles - tbase;
         const int ntj = (rem + QP_NW - 1) / QP_NW; /* same for every wavefront */
         if (ntj <= 1) factor_panel_update<1>(L, Dg, n, ld, J, tbase);
-        else if (ntj == 2) factor_panel_update<2>(L, Dg, n, ld, J, tbase);
-        else if (ntj == 3) factor_panel_update<3>(L, Dg, n, ld, J, tbase);
-        else factor_panel_update<4>(L, Dg, n, ld, J, tbase);
+        else factor_panel_update<2>(L, Dg, n, ld, J, tbase);
       }
     }
     __syncthreads();
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[4] += tq1 - tq0; tq0 = tq1; }
-    /* ---- (2) diagonal block: right-looking, lane = row (registers), columns exchanged via LDS - */
-    if (wid == 0) {
-      double p[QP_FNB];
-#pragma unroll
-      for (int c = 0; c < NB; c++) p[c] = (lane < jb && c <= lane && !(dbgf & 16)) ? L[(size_t)(J + c) * ld + (J + lane)] : 1.0 + (c == lane);
-#pragma unroll
-      for (int c = 0; c < NB; c++) {
-        if (c < jb && !(dbgf & 8)) {
-          if (lane < NB) F.colbuf[lane] = p[c]; /* un-normalised column c */
-          QP_WAVE_SYNC();
-          const double dc = F.colbuf[c];
-          const double lic = p[c] / dc;
-#pragma unroll
-          for (int c2 = c + 1; c2 < NB; c2++) p[c2] = QP_FMA(-lic, F.colbuf[c2], p[c2]);
-          if (lane > c) p[c] = lic;
-          QP_WAVE_SYNC();
+    /* ---- (2) diagonal block: right-looking LDL' inside LDS.  The tile is staged by all threads;
+     * wavefront 0 eliminates column by column (lane & 31 = row, the two half-waves take alternate
+     * target columns), rolled loop and unconditional LDS traffic: no per-column lane masks or
+     * addresses to keep alive under the 128-VGPR cap.  Same FMAs per entry as the register version:
+     * p(r,c2) <- fma(-l(r,c), p(c2,c), p(r,c2)) for c ascending, l(r,c) = p(r,c) / p(c,c). ---------- */
+    for (int e = tid; e < NB * NB; e += QP_T) {
+      const int c = e / NB, r = e % NB;
+      F.Ld[r][c] = (r >= c && r < jb && !(dbgf & 16)) ? L[(size_t)(J + c) * ld + (J + r)] : ((r == c) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wid == 0 && !(dbgf & 8)) {
+#pragma unroll 1
+      for (int c = 0; c < jb; c++) {
+        const int ln = QP_FRESH_LANE(lane);
+        const int r = ln & (NB - 1), h = ln >> 5;
+        const double dc = F.Ld[c][c];
+        const double prc = F.Ld[r][c];
+        const double lic = (r > c) ? prc / dc : 0.0; /* rows <= c: no-op updates below */
+#pragma unroll 4
+        for (int c2 = c + 1 + h; c2 < NB; c2 += 2) {
+          const double t = QP_FMA(-lic, F.Ld[c2][c], F.Ld[r][c2]);
+          if (r >= c2) F.Ld[r][c2] = t;
         }
-      }
-      if (lane < jb) {
-#pragma unroll
-        for (int c = 0; c < NB; c++) {
-          if (c < lane) { F.Ld[lane][c] = p[c]; L[(size_t)(J + c) * ld + (J + lane)] = p[c]; }
-          if (c == lane) { F.dv[c] = 1.0 / p[c]; Dg[J + c] = p[c]; } /* reciprocal pivot for the panel rows */
+        QP_WAVE_SYNC();
+        if (h == 0) {
+          if (r > c) F.Ld[r][c] = lic;
+          if (r == c) { F.dv[c] = 1.0 / dc; F.dg[c] = dc; } /* reciprocal pivot for the panel rows */
         }
+        QP_WAVE_SYNC();
       }
     }
     __syncthreads();
+    for (int e = tid; e < jb * jb; e += QP_T) {
+      const int c = e / jb, r = e % jb;
+      if (r > c) L[(size_t)(J + c) * ld + (J + r)] = F.Ld[r][c];
+    }
+    if (tid < jb) Dg[J + tid] = F.dg[tid];
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
     /* ---- (3) rows below the block: l_ic = (p_ic - sum_{c1<c} u_ic1 l_c,c1) / d_c ---------------- */
 #pragma unroll 1
@@ -335,7 +345,7 @@ struct SolveLds {
   double part[QP_SNB];
 };
 
-QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *xg, char *lds, int lds_bytes) {
+QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *xg, char *lds, int lds_bytes, int64_t *tdbg = nullptr) {
   SolveLds &T = *(SolveLds *)lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_SNB;
@@ -343,35 +353,50 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
   __syncthreads();
   if (xs != xg) for (int i = tid; i < n; i += QP_T) xs[i] = xg[i];
   /* forward: L y = b */
+  long long ts0 = QP_CLOCK();
   for (int J = 0; J < n; J += NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
-    for (int e = tid; e < jb * jb; e += QP_T) {
-      const int c = e / jb, r = e % jb;
-      if (r > c) T.tile[r][c] = L[(size_t)(J + c) * ld + (J + r)];
+    for (int e = tid; e < NB * NB; e += QP_T) { /* strict lower triangle, zero elsewhere: the block solve reads it unconditionally */
+      const int c = e / NB, r = e % NB;
+      T.tile[r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
     }
     __syncthreads();
-    if (wid == 0) { /* lane = row of the block; its row of L in registers, pivots broadcast by readlane */
+    if (wid == 0) { /* lane = row of the block; pivots broadcast by readlane; the row of L comes from LDS
+                     * eight entries at a time (small register arrays: the kernel runs under a 128-VGPR cap) */
+      const int ln = QP_FRESH_LANE(lane) & (NB - 1);
       double v = (lane < jb) ? xs[J + lane] : 0.0;
-      double trow[QP_SNB];
+      double tr[2][8];
 #pragma unroll
-      for (int c = 0; c < NB; c++) trow[c] = (lane < jb && c < lane) ? T.tile[lane][c] : 0.0;
+      for (int c = 0; c < 8; c++) tr[0][c] = T.tile[ln][c];
 #pragma unroll
-      for (int c = 0; c < NB; c++) {
-        const double yc = qp_readlane(v, c);
-        v = QP_FMA(-trow[c], yc, v);
+      for (int cb = 0; cb < NB; cb += 8) {
+        if (cb + 8 < NB) {
+#pragma unroll
+          for (int c = 0; c < 8; c++) tr[((cb >> 3) + 1) & 1][c] = T.tile[ln][cb + 8 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const double yc = qp_readlane(v, cb + c);
+          v = QP_FMA(-tr[(cb >> 3) & 1][c], yc, v);
+        }
       }
       if (lane < jb) xs[J + lane] = v;
     }
     __syncthreads();
-    for (int i = J + jb + tid; i < n; i += QP_T) { /* 32 independent column loads in flight per row */
-      double lv[QP_SNB];
-#pragma unroll
-      for (int cc = 0; cc < NB; cc++) lv[cc] = L[(size_t)(J + ((cc < jb) ? cc : jb - 1)) * ld + i];
+    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[8] += t - ts0; ts0 = t; }
+    for (int i = J + jb + tid; i < n; i += QP_T) { /* 16 independent column loads in flight per row */
       double acc = xs[i];
 #pragma unroll
-      for (int cc = 0; cc < NB; cc++) if (cc < jb) acc = QP_FMA(-lv[cc], xs[J + cc], acc);
+      for (int ch = 0; ch < NB; ch += 16) {
+        double lv[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) lv[cc] = L[(size_t)(J + ((ch + cc < jb) ? ch + cc : jb - 1)) * ld + i];
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) if (ch + cc < jb) acc = QP_FMA(-lv[cc], xs[J + ch + cc], acc);
+      }
       xs[i] = acc;
     }
+    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[9] += t - ts0; ts0 = t; }
   }
   __syncthreads();
   for (int i = tid; i < n; i += QP_T) xs[i] = xs[i] / Dg[i];
@@ -408,24 +433,34 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
         if (lane == 0 && c < jb) T.part[c] = sv;
       }
     }
-    for (int e = tid; e < jb * jb; e += QP_T) {
-      const int c = e / jb, r = e % jb;
-      if (r > c) T.tile[r][c] = L[(size_t)(J + c) * ld + (J + r)];
+    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[10] += t - ts0; ts0 = t; }
+    for (int e = tid; e < NB * NB; e += QP_T) {
+      const int c = e / NB, r = e % NB;
+      T.tile[r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
     }
     __syncthreads();
-    if (wid == 0) { /* lane = column of the block: holds L(J+c, J+lane) for c > lane */
+    if (wid == 0) { /* lane = column of the block: needs L(J+c, J+lane) for c > lane, eight at a time from LDS */
+      const int ln = QP_FRESH_LANE(lane) & (NB - 1);
       double v = (lane < jb) ? (xs[J + lane] - T.part[lane]) : 0.0;
-      double tcol[QP_SNB];
+      double tc[2][8];
 #pragma unroll
-      for (int c = 0; c < NB; c++) tcol[c] = (c < jb && lane < c) ? T.tile[c][lane] : 0.0;
+      for (int c = 0; c < 8; c++) tc[0][c] = T.tile[NB - 1 - c][ln];
 #pragma unroll
-      for (int c = NB - 1; c >= 0; c--) {
-        const double xc = qp_readlane(v, c);
-        v = QP_FMA(-tcol[c], xc, v);
+      for (int cb = 0; cb < NB; cb += 8) { /* columns NB-1-cb .. NB-8-cb, descending */
+        if (cb + 8 < NB) {
+#pragma unroll
+          for (int c = 0; c < 8; c++) tc[((cb >> 3) + 1) & 1][c] = T.tile[NB - 1 - (cb + 8 + c)][ln];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const double xc = qp_readlane(v, NB - 1 - (cb + c));
+          v = QP_FMA(-tc[(cb >> 3) & 1][c], xc, v);
+        }
       }
       if (lane < jb) xs[J + lane] = v;
     }
     __syncthreads();
+    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[11] += t - ts0; ts0 = t; }
   }
   if (xs != xg) for (int i = tid; i < n; i += QP_T) xg[i] = xs[i];
   __syncthreads();

@@ -547,7 +547,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
       I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
-      for (int k = 0; k < 8; k++) I.s.ticks_dbg[k] = 0;
+      for (int k = 0; k < 16; k++) I.s.ticks_dbg[k] = 0;
     }
     __syncthreads();
   }
@@ -562,6 +562,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     if (executed >= budget) break;
     executed++;
     QP_OPAQUE(a.b);
+    const long long tr0 = QP_CLOCK();
     /* ---- dx-dependent quantities of is_dual_infeasible (termination.c:190-203) -------------- */
     double vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
     for (int j = tid; j < n; j += QP_T) {
@@ -642,6 +643,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       vs[2] += a.q()[j] * dx;
     }
     block_reduce<8, 3>(I.S, vm, vs);
+    if (tid == 0) I.s.ticks_dbg[12] += QP_CLOCK() - tr0;
     /* ---- decision: check_termination + the branch of qpalm.c:488-676 ------------------------- */
     if (tid == 0) {
       qpg_scalars &s = I.s;
@@ -757,7 +759,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
       for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
       __syncthreads();
-      dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes);
+      dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg);
       const long long t2 = QP_CLOCK();
       for (int i = tid; i < m; i += QP_T) a.active_old()[i] = a.active()[i];
       if (tid == 0) {

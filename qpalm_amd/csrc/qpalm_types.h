@@ -51,7 +51,7 @@ typedef struct {
   /* work counters (device side statistics for the roofline accounting in bench.py) */
   int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_spmv;
   int64_t ticks_total, ticks_factor, ticks_update, ticks_solve, ticks_linesearch, ticks_resid;
-  int64_t ticks_dbg[8]; /* fine-grained phase timers (100 MHz ticks), see QPGStats.ms_dbg */
+  int64_t ticks_dbg[16]; /* fine-grained phase timers (100 MHz ticks), see QPGStats.ms_dbg */
 } qpg_scalars;
 
 /* view of one batch in device memory; passed by value to the kernels */
