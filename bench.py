@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--dbg-flags", type=int, default=0, help="timing experiments only (results wrong)")
     args = ap.parse_args()
 
@@ -112,6 +113,8 @@ def main():
     ctx.set_option("update_rank_threshold", args.rank_threshold)
     if args.dbg_flags:
         ctx.set_option("dbg_flags", args.dbg_flags)
+    if args.max_slots:
+        ctx.set_option("max_slots", args.max_slots)
     B, n, m = args.batch, args.n, args.m
     settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     dens_A = 0.01 if n >= 400 else max(0.01, 4.0 / n)

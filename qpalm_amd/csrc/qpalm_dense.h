@@ -605,14 +605,12 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
           /* unrolled by the queue depth: slot u of the queue is a fixed register, so the load
            * issued QD columns ago is the only one waited for (rotating the queue through register
            * moves would make every column wait for the newest load) */
-#pragma unroll 1
-          for (int c0 = 0; c0 < NB; c0 += QD) {
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
 #pragma unroll
             for (int u = 0; u < QD; u++) {
               const int c1 = c0 + u;
               double l = q[u];
               const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
-              q[u] = rowp[(size_t)cpre * cstride];
 #pragma unroll
               for (int rb = 0; rb < K; rb += 8) {
                 double cw[8], cg[8];
@@ -628,8 +626,15 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
               }
               rowp[(size_t)c1 * cstride] = l;
               QP_SCHED_BARRIER();
+              q[u] = rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
+              QP_SCHED_BARRIER();
             }
-          }
+          };
+          /* first group peeled: the loop is then entered with as many memory operations in flight as
+           * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
+          group(0);
+#pragma unroll 1
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
         }
         double dreg = (lane < jb) ? U.dd[cur][lane] : 1.0;          /* lane c holds the pivot of column c */
         double lnext = (lane > 0 && lane < jb) ? U.Ld[cur][lane][0] : 0.0;

@@ -38,6 +38,7 @@ typedef emu_double4 qp_double4;
 #define QP_UNIFORM(x) (x)
 #define QP_OPAQUE(x) do { } while (0)
 #define QP_FRESH_LANE(lane) (lane)
+#define QP_ALWAYS_INLINE
 #else
 typedef double qp_double4 __attribute__((ext_vector_type(4)));
 #define QP_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -57,6 +58,7 @@ static __device__ __forceinline__ int qp_fresh_lane_() {
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
 }
 #define QP_FRESH_LANE(lane) qp_fresh_lane_()
+#define QP_ALWAYS_INLINE __attribute__((always_inline))
 #endif
 
 /* ---- c_max / c_min / c_absval exactly as the reference's macros (include/global_opts.h) ---- */
