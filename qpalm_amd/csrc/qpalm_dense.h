@@ -345,13 +345,21 @@ struct SolveLds {
   double part[QP_SNB];
 };
 
-QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *xg, char *lds, int lds_bytes, int64_t *tdbg = nullptr) {
-  SolveLds &T = *(SolveLds *)lds;
+#ifndef QP_NI_SOLVE
+#define QP_NI_SOLVE QPNI
+#endif
+QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld, double *xg_, char *lds_, int lds_bytes, int64_t *tdbg = nullptr) {
+  const qp_gdouble *L = (const qp_gdouble *)L_, *Dg = (const qp_gdouble *)Dg_;
+  qp_gdouble *xg = (qp_gdouble *)xg_;
+  char QP_LDS_AS *lds = (char QP_LDS_AS *)lds_;
+  SolveLds QP_LDS_AS &T = *(SolveLds QP_LDS_AS *)lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_SNB;
-  double *xs = ((size_t)sizeof(SolveLds) + (size_t)n * 8 <= (size_t)lds_bytes) ? (double *)(lds + sizeof(SolveLds)) : xg;
+  /* the right-hand side always fits: n <= 4 QP_T and lds_bytes >= 64 KB (checked by the host) */
+  double QP_LDS_AS *xs = (double QP_LDS_AS *)(lds + sizeof(SolveLds));
+  (void)lds_bytes;
   __syncthreads();
-  if (xs != xg) for (int i = tid; i < n; i += QP_T) xs[i] = xg[i];
+  for (int i = tid; i < n; i += QP_T) xs[i] = xg[i];
   /* forward: L y = b */
   long long ts0 = QP_CLOCK();
   for (int J = 0; J < n; J += NB) {
@@ -418,7 +426,7 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
 #pragma unroll
         for (int q = 0; q < CW; q++) {
           const int c = wid + q * QP_NW;
-          const double *col = L + (size_t)(J + ((c < jb) ? c : jb - 1)) * ld;
+          const qp_gdouble *col = L + (size_t)(J + ((c < jb) ? c : jb - 1)) * ld;
           double lv[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; lv[u] = col[(i < n) ? i : n - 1]; }
@@ -462,7 +470,7 @@ QPN void dense_solve(const double *L, const double *Dg, int n, int ld, double *x
     __syncthreads();
     if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[11] += t - ts0; ts0 = t; }
   }
-  if (xs != xg) for (int i = tid; i < n; i += QP_T) xg[i] = xs[i];
+  for (int i = tid; i < n; i += QP_T) xg[i] = xs[i];
   __syncthreads();
 }
 

@@ -27,6 +27,18 @@
 #define QP_NW (QP_T / 64)
 #define QPD __device__ __forceinline__
 #define QPN __device__ __forceinline__
+/* a real call: the callee gets its own register allocation instead of inheriting the live values of
+ * the whole iteration loop.  Its pointer arguments are generic, so the callee re-types them (HBM arrays
+ * are global memory, the LDS block is LDS): flat accesses would tie vmcnt to lgkmcnt. */
+#ifdef QPALM_EMU
+#define QPNI __device__ inline
+typedef double qp_gdouble;
+#define QP_LDS_AS
+#else
+#define QPNI __device__ __noinline__
+typedef double __attribute__((address_space(1))) qp_gdouble;
+#define QP_LDS_AS __attribute__((address_space(3)))
+#endif
 
 #ifdef QPALM_EMU
 typedef emu_double4 qp_double4;

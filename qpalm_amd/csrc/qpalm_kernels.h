@@ -189,7 +189,7 @@ QPN void dev_compute_residuals(const qpg_view &V, const QpArrays &a, IterShared 
 
 /* single-QP boundary operations (include/solver_interface.h) on device-resident state */
 template <int RPT>
-__global__ __launch_bounds__(QP_T) void k_op(qpg_view V, int b, int op) {
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int op) {
   __shared__ IterShared I;
   char *lds = QP_DYN_LDS();
   const qpg_settings &st = *V.settings;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(QP_T) void k_spmv_generic(int nrows, const int *ptr
 /* Every QP of the batch: d = -(L D L')^{-1} dphi with its current factor, `reps` times.  This is
  * the stand-alone LDL^T-solve kernel the roofline line of bench.py measures (8.03 MB of
  * algorithmic traffic per QP and repetition at n = 1000). */
-__global__ __launch_bounds__(QP_T) void k_ldlsolve_all(qpg_view V, int reps) {
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_ldlsolve_all(qpg_view V, int reps) {
   char *lds = QP_DYN_LDS();
   for (int b = blockIdx.x; b < V.B && b < V.nslots; b += gridDim.x) {
     const QpArrays a = qp_arrays(V, b);
