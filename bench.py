@@ -23,6 +23,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+PMC_FILE = os.path.join(ROOT, "profiles", "r01", "k_solve_pmc_traffic.json")
+
+
+def pmc_traffic(batch, n, m):
+    """HBM bytes per k_solve launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected in
+    separate runs of this very command, corrected as MI355X_MICROARCH.md prescribes); None when no pass matches."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        if d["batch"] == batch and d["n"] == n and d["m"] == m:
+            return float(d["traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
 
 
 def algorithmic_bytes(n, m, nnzA, nnzQ, stats, iters):
@@ -85,7 +100,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "512")), help="QPs per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "2048")),
+                    help="QPs per GPU (512 resident factor slots = workgroups; the rest queue up behind them)")
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
@@ -196,7 +212,7 @@ def main():
                        "update_rank_threshold": args.rank_threshold},
             "roofline": {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes},
+                         "traffic": pmc_traffic(B, n, m) if world == 1 else None, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes},
             "ldl_solve": {"kernel": "k_ldlsolve_all", "qps": nsl, "ms": ms_ldl, "bytes": ldl_bytes,
                           "achieved": ldl_bytes / (ms_ldl * 1e-3) / 1e9, "unit": "GB/s",
                           "frac": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -19,7 +19,9 @@
 #ifdef QPALM_EMU
 #define QP_WAVE_SYNC() emu_wave_sync()
 #define QP_SCHED_BARRIER() do { } while (0)
+#define QP_SETPRIO(p) do { } while (0)
 #else
+#define QP_SETPRIO(p) __builtin_amdgcn_s_setprio(p) /* issue priority of a wavefront on its SIMD */
 /* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
 #define QP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define QP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -497,6 +499,35 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
  * arithmetic per entry is the same sequence of FMAs as without look-ahead.
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
+#ifndef QP_TQD
+#define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
+#endif
+/* R adjacent rows of one column: 16-byte accesses where R is even (the address is 16-byte aligned:
+ * row index and leading dimension are even, slots are 256-byte aligned) */
+#ifdef QPALM_EMU
+template <int R> QPD void qp_load_rows(const double *p, double *v) { for (int k = 0; k < R; k++) v[k] = p[k]; }
+template <int R> QPD void qp_store_rows(double *p, const double *v) { for (int k = 0; k < R; k++) p[k] = v[k]; }
+#else
+typedef double qp_double2 __attribute__((ext_vector_type(2)));
+template <int R> QPD void qp_load_rows(const double *p, double *v) {
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < R; k += 2) { const qp_double2 t = *(const qp_double2 *)(p + k); v[k] = t.x; v[k + 1] = t.y; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = p[k];
+  }
+}
+template <int R> QPD void qp_store_rows(double *p, const double *v) {
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < R; k += 2) { qp_double2 t; t.x = v[k]; t.y = v[k + 1]; *(qp_double2 *)(p + k) = t; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; k++) p[k] = v[k];
+  }
+}
+#endif
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
   double Ld[2][QP_UNB][QP_UNB + 1];
@@ -599,12 +630,14 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
       if (wid == 0) {
         /* ===== panel wave ===================================================================== */
         const long long tp0 = QP_CLOCK();
+        QP_SETPRIO(3); /* the serial chain of the sweep goes first on its SIMD */
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[cur][lane][r] : 0.0;
         if (s > 0) {
-          /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows */
-          constexpr int QD = 4;
+          /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
+           * deeper queue (one row per lane: registers to spare, and this wave is the critical path) */
+          constexpr int QD = 8;
           double *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
           const size_t cstride = (lane < jb) ? (size_t)ld : 0;
           double q[QD];
@@ -711,6 +744,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
           for (int r = 0; r < K; r++) w[rr][r] = own_live0 ? U.stash[rr][r][lane] : 0.0;
+        QP_SETPRIO(0);
         if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
       }
       if (wid != 0 || own_live0) {
@@ -724,31 +758,26 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
            * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
            * queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four ranks at a time.
            * Register budget <= 128 VGPRs so that two workgroups share a CU. */
-          constexpr int QD = 4;
-          double *rowp[RPT];
-          size_t cstride[RPT];
-          double q[RPT][QD];
+          constexpr int QD = QP_TQD;
+          /* the RPT adjacent rows of a thread are one access group: 16-byte loads/stores (RPT even),
+           * one address and one liveness per thread.  Rows n..ld-1 are padding of the panel (ld is a
+           * multiple of 8): they are carried along (w = 0 there, nobody reads them). */
+          const int i0 = tid * RPT;
+          const bool ok = (i0 >= Jn && i0 < ld);
+          double *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
+          const size_t cstride = ok ? (size_t)ld : 0;
+          double q[QD][RPT];
 #pragma unroll
-          for (int rr = 0; rr < RPT; rr++) {
-            const int i = tid * RPT + rr;
-            const bool ok = (i >= Jn && i < n);
-            rowp[rr] = ok ? (L + (size_t)Jp * ld + i) : (dummy + tid + rr * QP_T);
-            cstride[rr] = ok ? (size_t)ld : 0;
-#pragma unroll
-            for (int cc = 0; cc < QD; cc++) q[rr][cc] = rowp[rr][(size_t)cc * cstride[rr]];
-          }
-#pragma unroll 1
-          for (int c0 = 0; c0 < NB; c0 += QD) {
+          for (int cc = 0; cc < QD; cc++) qp_load_rows<RPT>(rowp + (size_t)cc * cstride, q[cc]);
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
 #pragma unroll
             for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
-              const int c1 = c0 + u;
+              int c1 = c0 + u;
+              QP_OPAQUE(c1); /* addresses are recomputed from c1: no per-slot induction pointers (VGPR budget) */
               double l[RPT];
               const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
 #pragma unroll
-              for (int rr = 0; rr < RPT; rr++) {
-                l[rr] = q[rr][u];
-                q[rr][u] = rowp[rr][(size_t)cpre * cstride[rr]];
-              }
+              for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
 #pragma unroll
               for (int rb = 0; rb < K; rb += 4) {
                 double cf[4][2];
@@ -766,10 +795,15 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
                 }
                 QP_SCHED_BARRIER();
               }
-#pragma unroll
-              for (int rr = 0; rr < RPT; rr++) rowp[rr][(size_t)c1 * cstride[rr]] = l[rr];
+              qp_store_rows<RPT>(rowp + (size_t)c1 * cstride, l);
+              QP_SCHED_BARRIER();
+              qp_load_rows<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
+              QP_SCHED_BARRIER();
             }
-          }
+          };
+          group(0); /* peeled, see the panel wave's loop */
+#pragma unroll 1
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
         }
         /* rows of block s+1 to the hand-over buffer of the next phase */
 #pragma unroll
