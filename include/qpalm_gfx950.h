@@ -109,7 +109,8 @@ typedef struct {
   qpg_float ms_total, ms_factor, ms_update, ms_solve, ms_linesearch;
   qpg_float ms_dbg[16]; /* update: 0 staging, 1 panel wave busy, 2 last trailing wave busy, 7 sweep phases (wall);
                            factor: 3 form, 4 panel gemm, 5 block, 6 panel solve;
-                           solve: 8 forward block, 9 forward rows below, 10 backward dots, 11 backward block; 12 SpMV+residuals */
+                           solve: 8 forward block, 9 forward rows below, 10 backward dots, 11 backward block; 12 SpMV+residuals;
+                           line search: 13 SpMVs, 14 breakpoints + compaction, 15 sort (the scan is the rest) */
 } QPGStats;
 
 typedef struct qpg_ctx qpg_ctx;

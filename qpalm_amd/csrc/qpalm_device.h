@@ -191,20 +191,55 @@ QPD void block_compact2(QpShared &S, int count, F0 f0, F1 f1, int *out0, int *ou
 /* y[r] = sum_k val[k] * x[idx[k]], k in [ptr[r], ptr[r+1]) -- one sub-wavefront of G lanes per
  * compressed column/row, coalesced walk of idx/val, butterfly reduce.  Used for A'*yh (CSC of A),
  * A*d (CSC of A') and Q*d (full symmetric pattern).  post(r, sum) consumes the result. */
+#ifndef QP_SPMV_ROWS
+#define QP_SPMV_ROWS 4 /* rows in flight per lane group; 8 spills under the 128-VGPR cap (measured slower) */
+#endif
 template <int G, class Post>
 QPD void spmv_rows(int nrows, const int *__restrict__ ptr, const int *__restrict__ idx,
                    const double *__restrict__ val, const double *x, Post post) {
+  /* Every dependent global load costs 0.5-1.5 us here, and a row is a chain of three (pointer ->
+   * index/value -> x[index]).  So each group of G lanes walks U rows at once with branch-free,
+   * clamped loads: the U chains are in flight together.  Per row the arithmetic is unchanged: lane
+   * `sub` accumulates entries sub, sub+G, ... in order, then the xor tree. */
+  constexpr int U = QP_SPMV_ROWS, RG = QP_T / G;
   const int sub = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-  for (int r0 = 0; r0 < nrows; r0 += QP_T / G) {
-    const int r = r0 + grp;
-    double acc = 0.0;
-    if (r < nrows) {
-      const int k1 = ptr[r + 1];
-      for (int k = ptr[r] + sub; k < k1; k += G) acc = QP_FMA(val[k], x[idx[k]], acc);
+  for (int r0 = 0; r0 < nrows; r0 += U * RG) {
+    int k[U], k1[U];
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = r0 + grp + u * RG;
+      const bool valid = r < nrows;
+      k[u] = valid ? ptr[r] + sub : 0;
+      k1[u] = valid ? ptr[r + 1] : 0;
+      acc[u] = 0.0;
+    }
+    while (true) {
+      bool more = false;
+#pragma unroll
+      for (int u = 0; u < U; u++) more = more || (k[u] < k1[u]);
+      if (!more) break;
+      double vv[U], xx[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int kk = (k[u] < k1[u]) ? k[u] : 0; /* clamped: entry 0 always exists when any row has work */
+        vv[u] = val[kk];
+        xx[u] = x[idx[kk]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (k[u] < k1[u]) acc[u] = QP_FMA(vv[u], xx[u], acc[u]);
+        k[u] += G;
+      }
     }
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (r < nrows && sub == 0) post(r, acc);
+    for (int u = 0; u < U; u++) {
+      double a = acc[u];
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+      const int r = r0 + grp + u * RG;
+      if (r < nrows && sub == 0) post(r, a);
+    }
   }
 }
 

@@ -403,9 +403,11 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   const double ginv = 1 / I.s.gamma;
   const int prox = (int)st.proximal;
   __syncthreads();
+  long long tl0 = QP_CLOCK();
   spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), a.d(), [&](int r, double s) { a.Qd()[r] = prox ? (s + ginv * a.d()[r]) : s; });
   spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), a.d(), [&](int r, double s) { a.Ad()[r] = s; });
   __syncthreads();
+  if (tid == 0) { const long long t = QP_CLOCK(); I.s.ticks_dbg[13] += t - tl0; tl0 = t; } /* 13: line-search SpMVs */
   double vm[1] = {0.0}, vs[4] = {0.0, 0.0, 0.0, 0.0};
   for (int j = tid; j < n; j += QP_T) { vs[0] += a.d()[j] * a.Qd()[j]; vs[1] += a.d()[j] * a.df()[j]; }
   /* delta, alpha, s = alpha/delta for the 2m breakpoints; J = L xor P sums */
@@ -460,6 +462,7 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   if (P < 2) P = 2;
   for (int e = nL + tid; e < P; e += QP_T) { keys[e] = 1e300 * 1e300; idx[e] = 0x7fffffff; }
   __syncthreads();
+  if (tid == 0) { const long long t = QP_CLOCK(); I.s.ticks_dbg[14] += t - tl0; tl0 = t; } /* 14: breakpoints + compaction */
   /* bitonic sort ascending by (key, idx) */
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -473,6 +476,7 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
       __syncthreads();
     }
   }
+  if (tid == 0) { const long long t = QP_CLOCK(); I.s.ticks_dbg[15] += t - tl0; tl0 = t; } /* 15: sort */
   /* running (a, b): element i contributes (+d^2, -d*alpha) if delta > 0 else (-d^2, +d*alpha) once
    * passed; tau = -b/a at the first sorted breakpoint where a*s + b > 0 (linesearch.c:90-118) */
   const int CH = (nL + QP_T - 1) / QP_T > 0 ? (nL + QP_T - 1) / QP_T : 1;
