@@ -430,11 +430,13 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   /* compaction of L = {s > 0} into the sort buffer */
   int P2 = 1;
   while (P2 < 2 * m) P2 <<= 1;
-  double *keys; int *idx;
-  if ((size_t)P2 * 12 <= (size_t)V.lds_bytes) { keys = (double *)lds; idx = (int *)(lds + (size_t)P2 * 8); }
-  else { keys = a.ls_key() + 0; idx = a.ls_idx(); /* global fallback: keys are compacted in place below */ }
+  /* The sort buffer is LDS whenever 12 bytes per (power-of-two padded) breakpoint fit, else HBM.  The
+   * code is instantiated once per case so that the pointers have a KNOWN address space: a run-time
+   * select between the two makes them generic, and flat accesses to LDS made this phase 10x slower. */
   const bool in_lds = ((size_t)P2 * 12 <= (size_t)V.lds_bytes);
-  int nL = 0;
+  int nL = 0, mypos = 0x7fffffff;
+  double mytau = 0.0, ta = 0.0, tb = 0.0;
+  auto sort_and_scan = [&](auto keys, auto idx) QP_ALWAYS_INLINE {
   {
     int base = 0;
     for (int e0 = 0; e0 < 2 * m; e0 += QP_T) {
@@ -465,16 +467,18 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   if (tid == 0) { const long long t = QP_CLOCK(); I.s.ticks_dbg[14] += t - tl0; tl0 = t; } /* 14: breakpoints + compaction */
   /* bitonic sort ascending by (key, idx) */
   for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int j = k >> 1, lj = 31 - __builtin_clz(k >> 1); j > 0; j >>= 1, lj--) { /* j = 1 << lj: shifts, no integer division */
       for (int e = tid; e < (P >> 1); e += QP_T) {
-        const int i = ((e / j) * (j << 1)) + (e % j), p = i + j;
+        const int i = ((e >> lj) << (lj + 1)) + (e & (j - 1)), p = i + j;
         const bool up = ((i & k) == 0);
         const double ki = keys[i], kp = keys[p];
         const int ii = idx[i], ip = idx[p];
         if (ls_greater(ki, ii, kp, ip) == up) { keys[i] = kp; keys[p] = ki; idx[i] = ip; idx[p] = ii; }
       }
-      __syncthreads();
+      /* partners closer than 64 stay inside the 128 elements a wavefront owns in each round */
+      if (j > 32) __syncthreads(); else QP_WAVE_SYNC();
     }
+    __syncthreads();
   }
   if (tid == 0) { const long long t = QP_CLOCK(); I.s.ticks_dbg[15] += t - tl0; tl0 = t; } /* 15: sort */
   /* running (a, b): element i contributes (+d^2, -d*alpha) if delta > 0 else (-d^2, +d*alpha) once
@@ -496,19 +500,20 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   __syncthreads();
   if (lane == 63) { I.scan_a[wid] = ia; I.scan_b[wid] = ib; }
   __syncthreads();
-  double wa = 0.0, wb = 0.0, ta = 0.0, tb = 0.0;
+  double wa = 0.0, wb = 0.0;
   for (int w = 0; w < QP_NW; w++) { if (w < wid) { wa += I.scan_a[w]; wb += I.scan_b[w]; } ta += I.scan_a[w]; tb += I.scan_b[w]; }
   double ea = __shfl_up(ia, 1), eb = __shfl_up(ib, 1); /* exclusive prefix inside the wavefront */
   if (lane == 0) { ea = 0.0; eb = 0.0; }
   double ra = a0 + (wa + ea), rb = b0 + (wb + eb); /* value before my first element */
-  int mypos = 0x7fffffff;
-  double mytau = 0.0;
   for (int e = e0; e < e1; e++) {
     if (mypos == 0x7fffffff && ra * keys[e] + rb > 0) { mypos = e; mytau = -rb / ra; }
     const int iz = idx[e];
     const double dl = a.ls_delta()[iz], al = a.ls_alpha()[iz];
     if (dl > 0) { ra = ra + dl * dl; rb = rb - dl * al; } else { ra = ra - dl * dl; rb = rb + dl * al; }
   }
+  };
+  if (in_lds) sort_and_scan((double *)lds, (int *)(lds + (size_t)P2 * 8));
+  else sort_and_scan(a.ls_key() + 0, a.ls_idx() + 0); /* keys are compacted in place */
   const int pos = block_imin(I.S, mypos);
   __syncthreads();
   if (pos == 0x7fffffff) { if (tid == 0) I.S.bc[0] = -(b0 + tb) / (a0 + ta); }
@@ -517,7 +522,6 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   const double tau = I.S.bc[0];
   if (tid == 0) { I.s.eta = eta; I.s.beta = beta; I.nL = nL; }
   __syncthreads();
-  (void)in_lds;
   return tau;
 }
 
