@@ -138,17 +138,12 @@ def main():
     probs = [random_qp(n, m, seed=1000 + rank * B + k, density_A=dens_A, density_M=dens_M) for k in range(B)]
     bt = QpalmBatch(ctx, probs, ctx.default_settings(**settings_kw))   # upload + Ruiz scaling: not timed
 
-    class _Dev:  # zero-copy torch view of a device array of the batch
-        def __init__(self, ptr, shape):
-            self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (ptr, False), "version": 3}
-
     def gather_solutions():
         if world == 1:
             return
-        px, _ = bt.device_ptr("solution_x")
-        py, _ = bt.device_ptr("solution_y")
-        tx = torch.as_tensor(_Dev(px, (B, n)), device="cuda:%d" % local)
-        ty = torch.as_tensor(_Dev(py, (B, m)), device="cuda:%d" % local)
+        from qpalm_amd.dist import device_view
+        tx = device_view(bt, "solution_x", (B, n), "cuda:%d" % local)   # zero-copy views of the HBM arrays
+        ty = device_view(bt, "solution_y", (B, m), "cuda:%d" % local)
         gx = [torch.empty_like(tx) for _ in range(world)] if rank == 0 else None
         gy = [torch.empty_like(ty) for _ in range(world)] if rank == 0 else None
         dist.gather(tx, gx, dst=0)

@@ -10,6 +10,22 @@ import numpy as np
 INFO_FIELDS = ("iter", "iter_out", "status_val", "pri_res_norm", "dua_res_norm", "dua2_res_norm", "objective")
 
 
+class _DeviceArray:
+    """__cuda_array_interface__ wrapper of a device array of the batch (fp64, C order)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f8", "data": (int(ptr), False), "version": 3}
+
+
+def device_view(batch, name, shape, device):
+    """Zero-copy torch view of a named HBM array of the batch (e.g. "solution_x", [B][n]): what the
+    RCCL gather of bench.py sends, no staging through the host."""
+    import torch
+    ptr, nbytes = batch.device_ptr(name)
+    assert int(np.prod(shape)) * 8 <= nbytes, (name, shape, nbytes)
+    return torch.as_tensor(_DeviceArray(ptr, shape), device=device)
+
+
 def shard_indices(nqp, world, rank):
     """Round-robin assignment: per-instance cost varies by >10x inside one problem family
     (simulations/results/journal_paper/randomMPCsequential2.tex:32-61), so contiguous shards are

@@ -11,6 +11,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Same order as bench.py: torch initialises the HIP runtime first, the solver library joins it.
+    # (The other way round torch reports "No HIP GPUs are available" in this image.)  No-op without a GPU.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

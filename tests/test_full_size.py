@@ -103,3 +103,24 @@ def test_full_size_properties(hip):
     assert all(int(bt.info(k).iter) < it0[k] for k in range(nb))
     # two eps = 1e-6 solutions of the same QP: close, not identical
     assert rel(x2, xs) <= 1e-4 and rel(y2, ys) <= 1e-3, (rel(x2, xs), rel(y2, ys))
+
+
+def test_device_views_for_the_rccl_gather(hip):
+    """bench.py gathers solution_x / solution_y with torch.distributed straight from HBM: the zero-copy
+    torch views must alias the batch's device arrays."""
+    import torch
+    from qpalm_amd.dist import device_view
+    n, m, nb = 1000, 2000, 4
+    probs = [bench_qp(n, m, 7000 + k) for k in range(nb)]
+    bt = QpalmBatch(hip, probs, hip.default_settings(**ST))
+    bt.solve()
+    xs, ys = bt.solution()
+    tx = device_view(bt, "solution_x", (nb, n), "cuda:0")
+    ty = device_view(bt, "solution_y", (nb, m), "cuda:0")
+    assert tx.dtype == torch.float64 and tx.is_cuda and tuple(tx.shape) == (nb, n)
+    assert np.array_equal(tx.cpu().numpy(), xs) and np.array_equal(ty.cpu().numpy(), ys)
+    # what rank 0 does with the gathered buffers
+    g = [torch.empty_like(tx) for _ in range(2)]
+    g[0].copy_(tx); g[1].copy_(tx)
+    torch.cuda.synchronize()
+    assert np.array_equal(g[1].cpu().numpy(), xs)
