@@ -342,6 +342,12 @@ QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *
  * HBM exactly twice (forward + backward), every read a coalesced column segment.
  * ------------------------------------------------------------------------------------------- */
 #define QP_SNB 32
+#ifndef QP_SOLVE_FCH
+#define QP_SOLVE_FCH 16 /* forward: column loads in flight per row */
+#endif
+#ifndef QP_SOLVE_BU
+#define QP_SOLVE_BU 4 /* backward dots: 64-row chunks per iteration */
+#endif
 struct SolveLds {
   double tile[QP_SNB][QP_SNB + 1];
   double part[QP_SNB];
@@ -394,15 +400,15 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
     }
     __syncthreads();
     if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[8] += t - ts0; ts0 = t; }
-    for (int i = J + jb + tid; i < n; i += QP_T) { /* 16 independent column loads in flight per row */
+    for (int i = J + jb + tid; i < n; i += QP_T) { /* QP_SOLVE_FCH independent column loads in flight per row */
       double acc = xs[i];
 #pragma unroll
-      for (int ch = 0; ch < NB; ch += 16) {
-        double lv[16];
+      for (int ch = 0; ch < NB; ch += QP_SOLVE_FCH) {
+        double lv[QP_SOLVE_FCH];
 #pragma unroll
-        for (int cc = 0; cc < 16; cc++) lv[cc] = L[(size_t)(J + ((ch + cc < jb) ? ch + cc : jb - 1)) * ld + i];
+        for (int cc = 0; cc < QP_SOLVE_FCH; cc++) lv[cc] = L[(size_t)(J + ((ch + cc < jb) ? ch + cc : jb - 1)) * ld + i];
 #pragma unroll
-        for (int cc = 0; cc < 16; cc++) if (ch + cc < jb) acc = QP_FMA(-lv[cc], xs[J + ch + cc], acc);
+        for (int cc = 0; cc < QP_SOLVE_FCH; cc++) if (ch + cc < jb) acc = QP_FMA(-lv[cc], xs[J + ch + cc], acc);
       }
       xs[i] = acc;
     }
@@ -421,19 +427,20 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
       double sacc[CW];
 #pragma unroll
       for (int q = 0; q < CW; q++) sacc[q] = 0.0;
-      for (int i0 = J + jb; i0 < n; i0 += 256) {
-        double xv[4];
+      constexpr int BU = QP_SOLVE_BU; /* row chunks of 64 per iteration: CW * BU independent loads per lane */
+      for (int i0 = J + jb; i0 < n; i0 += 64 * BU) {
+        double xv[BU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; xv[u] = (i < n) ? xs[i] : 0.0; }
+        for (int u = 0; u < BU; u++) { const int i = i0 + 64 * u + lane; xv[u] = (i < n) ? xs[i] : 0.0; }
 #pragma unroll
         for (int q = 0; q < CW; q++) {
           const int c = wid + q * QP_NW;
           const qp_gdouble *col = L + (size_t)(J + ((c < jb) ? c : jb - 1)) * ld;
-          double lv[4];
+          double lv[BU];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; lv[u] = col[(i < n) ? i : n - 1]; }
+          for (int u = 0; u < BU; u++) { const int i = i0 + 64 * u + lane; lv[u] = col[(i < n) ? i : n - 1]; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) sacc[q] = QP_FMA(lv[u], xv[u], sacc[q]);
+          for (int u = 0; u < BU; u++) sacc[q] = QP_FMA(lv[u], xv[u], sacc[q]);
         }
       }
 #pragma unroll
