@@ -29,7 +29,11 @@ def build_hip(force=False, verbose=False):
     if not force and not _stale(LIB, _deps()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -enable-ipra=0: with LLVM's inter-procedural register allocation a kernel that calls two device
+    # functions faulted on the GPU (clean with one callee, in the emulator and fully inlined), and every
+    # edit inside a callee re-allocated the caller; the standard calling convention keeps phases independent.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-mllvm", "-enable-ipra=0",
            "-Wno-unused-value", "-o", LIB, os.path.join(CSRC, "qpalm_gfx950.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -182,7 +182,7 @@ struct FactorLds {
  * (tile index J/16 + wid + NW*t): branch-free k loop, fragments of step k+4 are in flight while the
  * 2*NTJ MFMAs of step k execute. */
 template <int NTJ>
-QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J, int tbase) {
+QPD void factor_panel_update(qp_gdouble *L, const qp_gdouble *Dg, int n, int ld, int J, int tbase) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int tile0 = J / 16 + tbase + wid;
@@ -205,7 +205,7 @@ QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J, 
     double pa[2][2], bv[2][NTJ];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const double *colk = L + (size_t)(4 * h + l4) * ld;
+      const qp_gdouble *colk = L + (size_t)(4 * h + l4) * ld;
       const double dk = Dg[4 * h + l4];
       pa[h][0] = -(colk[rowp0] * dk); pa[h][1] = -(colk[rowp1] * dk);
 #pragma unroll
@@ -217,7 +217,7 @@ QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J, 
       double na[2][2], nb[2][NTJ], nd[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const double *colk = L + (size_t)(kn + 4 * h + l4) * ld;
+        const qp_gdouble *colk = L + (size_t)(kn + 4 * h + l4) * ld;
         nd[h] = Dg[kn + 4 * h + l4];
         na[h][0] = colk[rowp0]; na[h][1] = colk[rowp1];
 #pragma unroll
@@ -254,8 +254,12 @@ QPD void factor_panel_update(double *L, const double *Dg, int n, int ld, int J, 
 }
 
 template <int RPT>
-QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *tdbg, int dbgf = 0) {
-  FactorLds &F = *(FactorLds *)lds;
+#ifndef QP_NI_FACTOR
+#define QP_NI_FACTOR QPNI
+#endif
+QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n, int ld, char *lds_, int64_t *tdbg, int dbgf = 0) {
+  qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_;
+  FactorLds QP_LDS_AS &F = *(FactorLds QP_LDS_AS *)lds_;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_FNB;
   __syncthreads();
@@ -349,7 +353,7 @@ QPN void dense_factor(double *L, double *Dg, int n, int ld, char *lds, int64_t *
 #define QP_SOLVE_BU 4 /* backward dots: 64-row chunks per iteration */
 #endif
 struct SolveLds {
-  double tile[QP_SNB][QP_SNB + 1];
+  double tile[2][QP_SNB][QP_SNB + 1]; /* forward: the next diagonal block is fetched while the current one is solved */
   double part[QP_SNB];
 };
 
@@ -370,25 +374,34 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
   for (int i = tid; i < n; i += QP_T) xs[i] = xg[i];
   /* forward: L y = b */
   long long ts0 = QP_CLOCK();
+  /* strict lower triangle of a diagonal block into a tile, zero elsewhere (the block solve reads it
+   * unconditionally); t0/nt = this thread's index / count among the loading threads */
+  auto load_tile = [&](const int J, const int buf, const int t0, const int nt) QP_ALWAYS_INLINE {
+    const int jb = (n - J < NB) ? (n - J) : NB;
+    for (int e = t0; e < NB * NB; e += nt) {
+      const int c = e / NB, r = e % NB;
+      T.tile[buf][r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+    }
+  };
+  load_tile(0, 0, tid, QP_T);
   for (int J = 0; J < n; J += NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
-    for (int e = tid; e < NB * NB; e += QP_T) { /* strict lower triangle, zero elsewhere: the block solve reads it unconditionally */
-      const int c = e / NB, r = e % NB;
-      T.tile[r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
-    }
+    const int cur = (J / NB) & 1;
     __syncthreads();
+    /* wavefronts 1.. fetch the next diagonal block while wavefront 0 solves this one */
+    if (QP_NW > 1 && wid != 0 && J + NB < n) load_tile(J + NB, cur ^ 1, tid - 64, QP_T - 64);
     if (wid == 0) { /* lane = row of the block; pivots broadcast by readlane; the row of L comes from LDS
                      * eight entries at a time (small register arrays: the kernel runs under a 128-VGPR cap) */
       const int ln = QP_FRESH_LANE(lane) & (NB - 1);
       double v = (lane < jb) ? xs[J + lane] : 0.0;
       double tr[2][8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) tr[0][c] = T.tile[ln][c];
+      for (int c = 0; c < 8; c++) tr[0][c] = T.tile[cur][ln][c];
 #pragma unroll
       for (int cb = 0; cb < NB; cb += 8) {
         if (cb + 8 < NB) {
 #pragma unroll
-          for (int c = 0; c < 8; c++) tr[((cb >> 3) + 1) & 1][c] = T.tile[ln][cb + 8 + c];
+          for (int c = 0; c < 8; c++) tr[((cb >> 3) + 1) & 1][c] = T.tile[cur][ln][cb + 8 + c];
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -397,6 +410,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
         }
       }
       if (lane < jb) xs[J + lane] = v;
+      if (QP_NW == 1 && J + NB < n) load_tile(J + NB, cur ^ 1, tid, QP_T);
     }
     __syncthreads();
     if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[8] += t - ts0; ts0 = t; }
@@ -421,6 +435,14 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
   const int Jlast = ((n - 1) / NB) * NB;
   for (int J = Jlast; J >= 0; J -= NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
+    /* the diagonal block's entries are requested first (registers), so their latency overlaps the dots */
+    constexpr int TE = (QP_SNB * QP_SNB + QP_T - 1) / QP_T;
+    double tv[TE];
+#pragma unroll
+    for (int k = 0; k < TE; k++) {
+      const int e = tid + k * QP_T, c = e / NB, r = e % NB;
+      tv[k] = (e < NB * NB && r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+    }
     { /* partial dots of the block's columns with x below the block: the NB/NW columns of this
        * wavefront advance together, 4 x 64 rows per iteration => 16 independent loads per lane */
       constexpr int CW = QP_SNB / QP_NW > 0 ? QP_SNB / QP_NW : 1;
@@ -451,9 +473,10 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
       }
     }
     if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[10] += t - ts0; ts0 = t; }
-    for (int e = tid; e < NB * NB; e += QP_T) {
-      const int c = e / NB, r = e % NB;
-      T.tile[r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+#pragma unroll
+    for (int k = 0; k < TE; k++) {
+      const int e = tid + k * QP_T, c = e / NB, r = e % NB;
+      if (e < NB * NB) T.tile[0][r][c] = tv[k];
     }
     __syncthreads();
     if (wid == 0) { /* lane = column of the block: needs L(J+c, J+lane) for c > lane, eight at a time from LDS */
@@ -461,12 +484,12 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
       double v = (lane < jb) ? (xs[J + lane] - T.part[lane]) : 0.0;
       double tc[2][8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) tc[0][c] = T.tile[NB - 1 - c][ln];
+      for (int c = 0; c < 8; c++) tc[0][c] = T.tile[0][NB - 1 - c][ln];
 #pragma unroll
       for (int cb = 0; cb < NB; cb += 8) { /* columns NB-1-cb .. NB-8-cb, descending */
         if (cb + 8 < NB) {
 #pragma unroll
-          for (int c = 0; c < 8; c++) tc[((cb >> 3) + 1) & 1][c] = T.tile[NB - 1 - (cb + 8 + c)][ln];
+          for (int c = 0; c < 8; c++) tc[((cb >> 3) + 1) & 1][c] = T.tile[0][NB - 1 - (cb + 8 + c)][ln];
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
