@@ -15,6 +15,7 @@
  */
 #ifndef QPALM_DENSE_H
 #define QPALM_DENSE_H
+#include <type_traits>
 
 #ifdef QPALM_EMU
 #define QP_WAVE_SYNC() emu_wave_sync()
@@ -253,6 +254,47 @@ QPD void factor_panel_update(qp_gdouble *L, const qp_gdouble *Dg, int n, int ld,
   }
 }
 
+/* Step (3) of dense_factor as its own function: one row per thread, the row's 32 panel entries live
+ * in registers (64 VGPRs), L and 1/D of the diagonal block come as LDS broadcasts. */
+#ifndef QP_NI_FROWS
+#define QP_NI_FROWS QPNI
+#endif
+QP_NI_FROWS void factor_panel_rows(double *L_, char *lds_, const int n, const int ld, const int J, const int jb) {
+  qp_gdouble *L = (qp_gdouble *)L_;
+  FactorLds QP_LDS_AS &F = *(FactorLds QP_LDS_AS *)lds_;
+  constexpr int NB = QP_FNB;
+  /* FULL = all 32 columns exist (every block but possibly the last): no per-column conditionals */
+  auto rows = [&](auto full) QP_ALWAYS_INLINE {
+    constexpr bool FULL = decltype(full)::value;
+#pragma unroll 1
+    for (int i = J + jb + threadIdx.x; i < n; i += QP_T) {
+      qp_gdouble *base = L + (size_t)J * ld + i;
+      double u[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) u[c] = (FULL || c < jb) ? base[(size_t)c * ld] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (FULL || c < jb) {
+          double v = u[c];
+#pragma unroll
+          for (int c1 = 0; c1 < c; c1++) {
+            v = QP_FMA(-u[c1], F.Ld[c][c1], v);
+            if ((c1 & 7) == 7) QP_SCHED_BARRIER(); /* at most eight LDS operands in registers next to u[32] */
+          }
+          u[c] = v; /* un-normalised l*d */
+        }
+        QP_SCHED_BARRIER();
+      }
+      int ld2 = ld;
+      QP_OPAQUE_V(ld2); /* store addresses are recomputed: 32 live column pointers would cost 64 VGPRs */
+#pragma unroll
+      for (int c = 0; c < NB; c++)
+        if (FULL || c < jb) base[(size_t)c * ld2] = u[c] * F.dv[c];
+    }
+  };
+  if (jb == NB) rows(std::true_type()); else rows(std::false_type());
+}
+
 template <int RPT>
 #ifndef QP_NI_FACTOR
 #define QP_NI_FACTOR QPNI
@@ -317,24 +359,7 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n, int ld, char *lds
     if (tid < jb) Dg[J + tid] = F.dg[tid];
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
     /* ---- (3) rows below the block: l_ic = (p_ic - sum_{c1<c} u_ic1 l_c,c1) / d_c ---------------- */
-#pragma unroll 1
-    for (int i = J + jb + tid; i < n; i += QP_T) {
-      double u[QP_FNB];
-#pragma unroll
-      for (int c = 0; c < NB; c++) u[c] = (c < jb) ? L[(size_t)(J + c) * ld + i] : 0.0;
-#pragma unroll
-      for (int c = 0; c < NB; c++) {
-        if (c < jb) {
-          double v = u[c];
-#pragma unroll
-          for (int c1 = 0; c1 < c; c1++) v = QP_FMA(-u[c1], F.Ld[c][c1], v);
-          u[c] = v; /* un-normalised l*d */
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < NB; c++)
-        if (c < jb) L[(size_t)(J + c) * ld + i] = u[c] * F.dv[c];
-    }
+    factor_panel_rows(L_, lds_, n, ld, J, jb);
     __syncthreads();
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
   }

@@ -49,6 +49,7 @@ typedef emu_double4 qp_double4;
 #define QP_CLOCK() ((long long)wall_clock64())
 #define QP_UNIFORM(x) (x)
 #define QP_OPAQUE(x) do { } while (0)
+#define QP_OPAQUE_V(x) do { } while (0)
 #define QP_FRESH_LANE(lane) (lane)
 #define QP_ALWAYS_INLINE
 #else
@@ -62,6 +63,7 @@ extern __shared__ __attribute__((aligned(16))) char qp_dyn_lds_[];
 #define QP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x) /* value is wave-uniform: keep it in an SGPR */
 /* stops LICM/CSE from keeping ~100 per-array addresses live across the whole iteration loop */
 #define QP_OPAQUE(x) asm volatile("" : "+s"(x))
+#define QP_OPAQUE_V(x) asm volatile("" : "+v"(x)) /* same for a value that lives in a VGPR (function arguments) */
 /* the lane id recomputed on the spot (2 VALU ops): inside latency-critical loops this keeps lane-derived
  * LDS addresses and lane masks out of long-lived (= spilled, under the 128-VGPR cap) registers */
 static __device__ __forceinline__ int qp_fresh_lane_() {
