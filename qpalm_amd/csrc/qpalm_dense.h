@@ -182,8 +182,16 @@ struct FactorLds {
 /* Panel update of block column J for a wavefront that owns NTJ consecutive-strided 16-row tiles
  * (tile index J/16 + wid + NW*t): branch-free k loop, fragments of step k+4 are in flight while the
  * 2*NTJ MFMAs of step k execute. */
+#ifndef QP_NI_FGEMM
+#define QP_NI_FGEMM QPNI
+#endif
+#ifndef QP_FST
+#define QP_FST 2 /* stages of panel fragments in flight in the MFMA k loop; must divide 4 (J/8 is a multiple of 4) */
+#endif
 template <int NTJ>
-QPD void factor_panel_update(qp_gdouble *L, const qp_gdouble *Dg, int n, int ld, int J, int tbase) {
+QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n, int ld, int J, int tbase) {
+  qp_gdouble *L = (qp_gdouble *)L_;
+  const qp_gdouble *Dg = (const qp_gdouble *)Dg_;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int tile0 = J / 16 + tbase + wid;
@@ -202,42 +210,46 @@ QPD void factor_panel_update(qp_gdouble *L, const qp_gdouble *Dg, int n, int ld,
       }
   }
   const int rowp0 = (J + l15 < n) ? (J + l15) : (n - 1), rowp1 = (J + 16 + l15 < n) ? (J + 16 + l15) : (n - 1);
-  if (J > 0) { /* J is a multiple of 32: eight columns of L per iteration, the next eight already in flight */
-    double pa[2][2], bv[2][NTJ];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const qp_gdouble *colk = L + (size_t)(4 * h + l4) * ld;
-      const double dk = Dg[4 * h + l4];
-      pa[h][0] = -(colk[rowp0] * dk); pa[h][1] = -(colk[rowp1] * dk);
-#pragma unroll
-      for (int t = 0; t < NTJ; t++) bv[h][t] = colk[rowc[t]];
-    }
-#pragma unroll 1
-    for (int k = 0; k < J; k += 8) {
-      const int kn = (k + 8 < J) ? (k + 8) : k; /* last iteration re-reads its own fragments */
-      double na[2][2], nb[2][NTJ], nd[2];
+  if (J > 0) {
+    /* J is a multiple of 32.  Eight columns of L per stage (two MFMA k-steps); QP_FST stages of raw
+     * fragments stay in flight in fixed registers, each refilled right after its MFMAs were issued
+     * (the k loop is a chain of ~1.5 us global loads otherwise: 8 MFMAs per stage hide nothing). */
+    constexpr int S = QP_FST;
+    double ra[S][2][2], rb[S][2][NTJ], rd[S][2];
+    auto load = [&](const int st, const int k) QP_ALWAYS_INLINE {
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const qp_gdouble *colk = L + (size_t)(kn + 4 * h + l4) * ld;
-        nd[h] = Dg[kn + 4 * h + l4];
-        na[h][0] = colk[rowp0]; na[h][1] = colk[rowp1];
+        const qp_gdouble *colk = L + (size_t)(k + 4 * h + l4) * ld;
+        rd[st][h] = Dg[k + 4 * h + l4];
+        ra[st][h][0] = colk[rowp0]; ra[st][h][1] = colk[rowp1];
 #pragma unroll
-        for (int t = 0; t < NTJ; t++) nb[h][t] = colk[rowc[t]];
+        for (int t = 0; t < NTJ; t++) rb[st][h][t] = colk[rowc[t]];
       }
+    };
+    auto mma = [&](const int st) QP_ALWAYS_INLINE {
 #pragma unroll
-      for (int h = 0; h < 2; h++)
+      for (int h = 0; h < 2; h++) {
+        const double pa0 = -(ra[st][h][0] * rd[st][h]), pa1 = -(ra[st][h][1] * rd[st][h]);
 #pragma unroll
         for (int t = 0; t < NTJ; t++) {
-          acc[t][0] = QP_MFMA_F64(pa[h][0], bv[h][t], acc[t][0]);
-          acc[t][1] = QP_MFMA_F64(pa[h][1], bv[h][t], acc[t][1]);
+          acc[t][0] = QP_MFMA_F64(pa0, rb[st][h][t], acc[t][0]);
+          acc[t][1] = QP_MFMA_F64(pa1, rb[st][h][t], acc[t][1]);
         }
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        pa[h][0] = -(na[h][0] * nd[h]); pa[h][1] = -(na[h][1] * nd[h]);
-#pragma unroll
-        for (int t = 0; t < NTJ; t++) bv[h][t] = nb[h][t];
       }
-    }
+    };
+    auto group = [&](const int k) QP_ALWAYS_INLINE {
+#pragma unroll
+      for (int st = 0; st < S; st++) {
+        mma(st);
+        const int kn = k + 8 * (S + st);
+        load(st, (kn < J) ? kn : (J - 8)); /* past the end: a harmless re-read */
+      }
+    };
+#pragma unroll
+    for (int st = 0; st < S; st++) load(st, 8 * st); /* J >= 32 >= 8 S */
+    group(0); /* peeled: steady-state wait counts inside the loop */
+#pragma unroll 1
+    for (int k = 8 * S; k < J; k += 8 * S) group(k);
   }
 #pragma unroll
   for (int t = 0; t < NTJ; t++) {
@@ -314,8 +326,8 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n, int ld, char *lds
       for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW) {
         const int rem = ntiles - tbase;
         const int ntj = (rem + QP_NW - 1) / QP_NW; /* same for every wavefront */
-        if (ntj <= 1) factor_panel_update<1>(L, Dg, n, ld, J, tbase);
-        else factor_panel_update<2>(L, Dg, n, ld, J, tbase);
+        if (ntj <= 1) factor_panel_update<1>(L_, Dg_, n, ld, J, tbase);
+        else factor_panel_update<2>(L_, Dg_, n, ld, J, tbase);
       }
     }
     __syncthreads();
