@@ -189,7 +189,8 @@ struct FactorLds {
 #define QP_FST 2 /* stages of panel fragments in flight in the MFMA k loop; must divide 4 (J/8 is a multiple of 4) */
 #endif
 template <int NTJ>
-QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n, int ld, int J, int tbase) {
+QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n_, int ld_, int J_, int tbase_) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), J = QP_UNIFORM(J_), tbase = QP_UNIFORM(tbase_); /* wave-uniform arguments back to SGPRs */
   qp_gdouble *L = (qp_gdouble *)L_;
   const qp_gdouble *Dg = (const qp_gdouble *)Dg_;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -271,9 +272,10 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n, int l
 #ifndef QP_NI_FROWS
 #define QP_NI_FROWS QPNI
 #endif
-QP_NI_FROWS void factor_panel_rows(double *L_, char *lds_, const int n, const int ld, const int J, const int jb) {
+QP_NI_FROWS void factor_panel_rows(double *L_, char *lds_, const int n_, const int ld_, const int J_, const int jb_) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), J = QP_UNIFORM(J_), jb = QP_UNIFORM(jb_); /* wave-uniform arguments back to SGPRs */
   qp_gdouble *L = (qp_gdouble *)L_;
-  FactorLds QP_LDS_AS &F = *(FactorLds QP_LDS_AS *)lds_;
+  FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
   constexpr int NB = QP_FNB;
   /* FULL = all 32 columns exist (every block but possibly the last): no per-column conditionals */
   auto rows = [&](auto full) QP_ALWAYS_INLINE {
@@ -298,7 +300,7 @@ QP_NI_FROWS void factor_panel_rows(double *L_, char *lds_, const int n, const in
         QP_SCHED_BARRIER();
       }
       int ld2 = ld;
-      QP_OPAQUE_V(ld2); /* store addresses are recomputed: 32 live column pointers would cost 64 VGPRs */
+      QP_OPAQUE(ld2); /* store addresses are recomputed: 32 live column pointers would cost 64 VGPRs */
 #pragma unroll
       for (int c = 0; c < NB; c++)
         if (FULL || c < jb) base[(size_t)c * ld2] = u[c] * F.dv[c];
@@ -311,9 +313,11 @@ template <int RPT>
 #ifndef QP_NI_FACTOR
 #define QP_NI_FACTOR QPNI
 #endif
-QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n, int ld, char *lds_, int64_t *tdbg, int dbgf = 0) {
+QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *lds_, int64_t *tdbg_, int dbgf_ = 0) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), dbgf = QP_UNIFORM(dbgf_); /* wave-uniform arguments back to SGPRs */
+  int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* the timers live in the kernel's static LDS */
   qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_;
-  FactorLds QP_LDS_AS &F = *(FactorLds QP_LDS_AS *)lds_;
+  FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_FNB;
   __syncthreads();
@@ -397,10 +401,12 @@ struct SolveLds {
 #ifndef QP_NI_SOLVE
 #define QP_NI_SOLVE QPNI
 #endif
-QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld, double *xg_, char *lds_, int lds_bytes, int64_t *tdbg = nullptr) {
+QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld_, double *xg_, char *lds_, int lds_bytes, int64_t *tdbg_ = nullptr) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_); /* wave-uniform arguments back to SGPRs */
+  int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* null or the timers in the kernel's static LDS */
   const qp_gdouble *L = (const qp_gdouble *)L_, *Dg = (const qp_gdouble *)Dg_;
   qp_gdouble *xg = (qp_gdouble *)xg_;
-  char QP_LDS_AS *lds = (char QP_LDS_AS *)lds_;
+  char QP_LDS_AS *lds = QP_LDS_ARG(char, lds_);
   SolveLds QP_LDS_AS &T = *(SolveLds QP_LDS_AS *)lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_SNB;
@@ -572,23 +578,24 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n, int ld,
 /* R adjacent rows of one column: 16-byte accesses where R is even (the address is 16-byte aligned:
  * row index and leading dimension are even, slots are 256-byte aligned) */
 #ifdef QPALM_EMU
-template <int R> QPD void qp_load_rows(const double *p, double *v) { for (int k = 0; k < R; k++) v[k] = p[k]; }
-template <int R> QPD void qp_store_rows(double *p, const double *v) { for (int k = 0; k < R; k++) p[k] = v[k]; }
+template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) { for (int k = 0; k < R; k++) v[k] = p[k]; }
+template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) { for (int k = 0; k < R; k++) p[k] = v[k]; }
 #else
 typedef double qp_double2 __attribute__((ext_vector_type(2)));
-template <int R> QPD void qp_load_rows(const double *p, double *v) {
+typedef qp_double2 __attribute__((address_space(1))) qp_gdouble2;
+template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) {
   if (R % 2 == 0) {
 #pragma unroll
-    for (int k = 0; k < R; k += 2) { const qp_double2 t = *(const qp_double2 *)(p + k); v[k] = t.x; v[k + 1] = t.y; }
+    for (int k = 0; k < R; k += 2) { const qp_double2 t = *(const qp_gdouble2 *)(p + k); v[k] = t.x; v[k + 1] = t.y; }
   } else {
 #pragma unroll
     for (int k = 0; k < R; k++) v[k] = p[k];
   }
 }
-template <int R> QPD void qp_store_rows(double *p, const double *v) {
+template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) {
   if (R % 2 == 0) {
 #pragma unroll
-    for (int k = 0; k < R; k += 2) { qp_double2 t; t.x = v[k]; t.y = v[k + 1]; *(qp_double2 *)(p + k) = t; }
+    for (int k = 0; k < R; k += 2) { qp_double2 t; t.x = v[k]; t.y = v[k + 1]; *(qp_gdouble2 *)(p + k) = t; }
   } else {
 #pragma unroll
     for (int k = 0; k < R; k++) p[k] = v[k];
@@ -622,15 +629,27 @@ template <int N> QPD double qp_row_shr(double v) {
 #endif
 
 template <int RPT, int K>
-QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *cols, int n_up,
-                      const int *cols_dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
+#ifndef QP_NI_UPDOWN
+#define QP_NI_UPDOWN QPNI
+#endif
+/* a real function (own register allocation, see qpalm_device.h): plain pointer arguments, re-typed inside */
+QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *Atss_, const int n_, const int ld_,
+                               double *L_, double *Dg_, double *Wst_, const int *cols_, int n_up_,
+                               const int *cols_dn_, int n_dn_, QpShared *S_, char *lds, int64_t *tdbg_) {
+  /* arguments of a real function arrive in VGPRs; these are wave-uniform: back to SGPRs, so that the
+   * loops they bound are scalar loops (not exec-mask loops) and v_readlane indices are scalars */
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), n_up = QP_UNIFORM(n_up_), n_dn = QP_UNIFORM(n_dn_);
+  int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* the timers live in the kernel's static LDS */
+  const qp_gint *Atp = (const qp_gint *)Atp_, *Ati = (const qp_gint *)Ati_, *cols = (const qp_gint *)cols_, *cols_dn = (const qp_gint *)cols_dn_;
+  const qp_gdouble *Atss = (const qp_gdouble *)Atss_;
+  qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_, *Wst = (qp_gdouble *)Wst_;
+  QpShared &S = *S_; /* static LDS of the kernel, reached through a generic pointer (one small reduction) */
   static_assert(K <= 16, "rank block must fit one DPP row");
-  UpdownLds<RPT, K> &U = *(UpdownLds<RPT, K> *)lds;
+  typedef UpdownLds<RPT, K> UpdownLdsT;
+  UpdownLdsT QP_LDS_AS &U = *QP_LDS_ARG(UpdownLdsT, lds);
   static_assert(sizeof(UpdownLds<RPT, K>) <= 64 * 1024, "update scratch must fit the dynamic LDS (lds_bytes >= 64 KB)");
-  const int n = V.n, ld = V.ld, NB = QP_UNB;
+  const int NB = QP_UNB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
-  const double *Atss = V.Atss + (size_t)b * V.nnzA;
   const int nr = n_up + n_dn;
   for (int r0 = 0; r0 < nr; r0 += K) {
     const int kk = (nr - r0 < K) ? (nr - r0) : K;
@@ -648,7 +667,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
         jmin = (i < jmin) ? i : jmin;
       }
     }
-    jmin = block_imin(S, jmin);
+    jmin = QP_UNIFORM(block_imin(S, jmin)); /* same value in every lane: keep the block loops scalar */
     double w[RPT][K];
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
@@ -662,7 +681,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
     const int J0 = (jmin / NB) * NB;
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1; }
     const int nblk = (n - J0 + NB - 1) / NB;
-    double *dummy = Wst + (size_t)QPG_KMAX * n;
+    qp_gdouble *dummy = Wst + (size_t)QPG_KMAX * n;
     /* prologue: rows of block 0 to the hand-over buffer, diagonal block 0 to LDS */
     {
       const int jb0 = (n - J0 < NB) ? (n - J0) : NB;
@@ -705,7 +724,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
           /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
            * deeper queue (one row per lane: registers to spare, and this wave is the critical path) */
           constexpr int QD = 8;
-          double *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
+          qp_gdouble *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
           const size_t cstride = (lane < jb) ? (size_t)ld : 0;
           double q[QD];
 #pragma unroll
@@ -831,7 +850,7 @@ QPN void dense_updown(const qpg_view &V, int b, double *L, double *Dg, double *W
            * multiple of 8): they are carried along (w = 0 there, nobody reads them). */
           const int i0 = tid * RPT;
           const bool ok = (i0 >= Jn && i0 < ld);
-          double *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
+          qp_gdouble *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
           const size_t cstride = ok ? (size_t)ld : 0;
           double q[QD][RPT];
 #pragma unroll

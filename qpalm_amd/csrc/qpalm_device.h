@@ -33,11 +33,22 @@
 #ifdef QPALM_EMU
 #define QPNI __device__ inline
 typedef double qp_gdouble;
+typedef int qp_gint;
+#define QP_LDS_ARG(T, p) ((T *)(p))
 #define QP_LDS_AS
 #else
 #define QPNI __device__ __noinline__
 typedef double __attribute__((address_space(1))) qp_gdouble;
+typedef int __attribute__((address_space(1))) qp_gint;
 #define QP_LDS_AS __attribute__((address_space(3)))
+/* the LDS block handed to a real function: typed as LDS, its (wave-uniform) offset back in an SGPR and
+ * known to be 16-byte aligned, so that accesses are ds_*_b128 with scalar base */
+static __device__ __forceinline__ unsigned qp_lds_arg_offset_(char *p) {
+  const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(char QP_LDS_AS *)p);
+  __builtin_assume((a & 15u) == 0);
+  return a;
+}
+#define QP_LDS_ARG(T, p) ((T QP_LDS_AS *)(size_t)qp_lds_arg_offset_((char *)(p)))
 #endif
 
 #ifdef QPALM_EMU
@@ -56,7 +67,16 @@ typedef emu_double4 qp_double4;
 typedef double qp_double4 __attribute__((ext_vector_type(4)));
 #define QP_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 extern __shared__ __attribute__((aligned(16))) char qp_dyn_lds_[];
-#define QP_DYN_LDS() (qp_dyn_lds_)
+/* The dynamic LDS block as a pointer the optimiser cannot trace back to the symbol.  Otherwise
+ * inter-procedural constant propagation rewrites the `lds` argument of the real functions into the
+ * symbol itself, and a non-kernel function reaches dynamic LDS through a table in memory
+ * (llvm.amdgcn.dynlds.offset.table): an s_load + wait inside the serial loops. */
+static __device__ __forceinline__ char *qp_dyn_lds_opaque_() {
+  unsigned a = (unsigned)(size_t)(char __attribute__((address_space(3))) *)qp_dyn_lds_;
+  asm volatile("" : "+s"(a));
+  return (char *)(char __attribute__((address_space(3))) *)(size_t)a;
+}
+#define QP_DYN_LDS() (qp_dyn_lds_opaque_())
 #define QP_FMA(a, b, c) fma((a), (b), (c))
 #define QP_SQRT(x) sqrt(x)
 #define QP_CLOCK() ((long long)wall_clock64())

@@ -243,7 +243,8 @@ QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds, int64_t
 template <int RPT>
 QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *up, int n_up,
                     const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
-  dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V, b, L, Dg, Wst, up, n_up, dn, n_dn, S, lds, tdbg);
+  dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA,
+                                         V.n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg);
 }
 
 /* =============================================================================================
