@@ -740,6 +740,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
 #pragma unroll
               for (int rb = 0; rb < K; rb += 8) {
+                if (rb >= kk) break; /* ranks >= kk are exact no-ops (w = 0, gamma = 0): skipped, wave-uniform */
                 double cw[8], cg[8];
 #pragma unroll
                 for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
@@ -805,6 +806,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             double l = lcur;
 #pragma unroll
             for (int rb = 0; rb < K; rb += 8) {
+              if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
               double cw[8], cg[8];
 #pragma unroll
               for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][1] : 0.0; }
@@ -866,6 +868,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
 #pragma unroll
               for (int rb = 0; rb < K; rb += 4) {
+                if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
                 double cf[4][2];
 #pragma unroll
                 for (int r = 0; r < 4; r++) { cf[r][0] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
