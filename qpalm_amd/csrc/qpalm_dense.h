@@ -170,6 +170,33 @@ QPN double form_schur(const qpg_view &V, int b, double *Lslot, const bool GERSH,
  *  (2) the 32 x 32 diagonal block is factorised by wavefront 0 (lane = row, registers + shuffles);
  *  (3) rows below the block are finished one row per thread with the block's L, D from LDS.
  * ------------------------------------------------------------------------------------------- */
+/* R adjacent rows of one column: 16-byte accesses where R is even (the address is 16-byte aligned:
+ * row index and leading dimension are even, slots are 256-byte aligned) */
+#ifdef QPALM_EMU
+template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) { for (int k = 0; k < R; k++) v[k] = p[k]; }
+template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) { for (int k = 0; k < R; k++) p[k] = v[k]; }
+#else
+typedef double qp_double2 __attribute__((ext_vector_type(2)));
+typedef qp_double2 __attribute__((address_space(1))) qp_gdouble2;
+template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) {
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < R; k += 2) { const qp_double2 t = *(const qp_gdouble2 *)(p + k); v[k] = t.x; v[k + 1] = t.y; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = p[k];
+  }
+}
+template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) {
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < R; k += 2) { qp_double2 t; t.x = v[k]; t.y = v[k + 1]; *(qp_gdouble2 *)(p + k) = t; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; k++) p[k] = v[k];
+  }
+}
+#endif
 #define QP_FNB 32
 #define QP_FNT 2 /* row tiles per wavefront and pass of the panel update: 2 keeps accumulators + two fragment stages under 128 VGPRs */
 struct FactorLds {
@@ -188,6 +215,11 @@ struct FactorLds {
 #ifndef QP_FST
 #define QP_FST 2 /* stages of panel fragments in flight in the MFMA k loop; must divide 4 (J/8 is a multiple of 4) */
 #endif
+/* NTJ == 2 works on PAIRS of adjacent rows: the wavefront's 32-row group is split into its even
+ * and its odd rows (two MFMA row tiles), and the block's 32 rows likewise into two column tiles, so
+ * every fragment element pair is ONE 16-byte load (half the load instructions, full 128-byte lines):
+ * the k loop is bound by the vector-memory pipeline, not by the MFMAs.  Which MFMA lane handles which
+ * entry does not change any entry's sum (k ascending). */
 template <int NTJ>
 QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n_, int ld_, int J_, int tbase_) {
   const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), J = QP_UNIFORM(J_), tbase = QP_UNIFORM(tbase_); /* wave-uniform arguments back to SGPRs */
@@ -195,26 +227,29 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n_, int 
   const qp_gdouble *Dg = (const qp_gdouble *)Dg_;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int tile0 = J / 16 + tbase + wid;
+  constexpr bool PAIR = (NTJ == 2);
+  /* rows of this wavefront: NTJ == 2: 32 consecutive rows from rbase, tile t = rows rbase + 2 j + t;
+   * NTJ == 1: 16 consecutive rows.  Block rows (A operand): column tile ct = rows J + 2 i + ct. */
+  const int rbase = (J / 16 + tbase) * 16 + wid * 16 * NTJ;
+  auto rowof = [&](const int t, const int j) QP_ALWAYS_INLINE { return PAIR ? (rbase + 2 * j + t) : (rbase + j); };
+  auto colof = [&](const int ct, const int i) QP_ALWAYS_INLINE { return J + 2 * i + ct; };
   qp_double4 acc[NTJ][2];
-  int rowc[NTJ];
 #pragma unroll
   for (int t = 0; t < NTJ; t++) {
-    const int row = (tile0 + t * QP_NW) * 16 + l15;
-    rowc[t] = (row < n) ? row : (n - 1);
+    const int row = rowof(t, l15);
 #pragma unroll
     for (int ct = 0; ct < 2; ct++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int col = J + ct * 16 + l4 + 4 * r;
+        const int col = colof(ct, l4 + 4 * r);
         acc[t][ct][r] = (row < n && col < n && row >= col) ? L[(size_t)col * ld + row] : 0.0;
       }
   }
-  const int rowp0 = (J + l15 < n) ? (J + l15) : (n - 1), rowp1 = (J + 16 + l15 < n) ? (J + 16 + l15) : (n - 1);
+  /* fragment addresses: a pair starts at an even row (16-byte aligned: ld is a multiple of 8); pairs
+   * that start beyond the matrix read rows 0/1 instead (their results are never written) */
+  const int rowb = PAIR ? ((rbase + 2 * l15 < n) ? rbase + 2 * l15 : 0) : ((rbase + l15 < n) ? rbase + l15 : n - 1);
+  const int rowa = (J + 2 * l15 < n) ? J + 2 * l15 : 0;
   if (J > 0) {
-    /* J is a multiple of 32.  Eight columns of L per stage (two MFMA k-steps); QP_FST stages of raw
-     * fragments stay in flight in fixed registers, each refilled right after its MFMAs were issued
-     * (the k loop is a chain of ~1.5 us global loads otherwise: 8 MFMAs per stage hide nothing). */
     constexpr int S = QP_FST;
     double ra[S][2][2], rb[S][2][NTJ], rd[S][2];
     auto load = [&](const int st, const int k) QP_ALWAYS_INLINE {
@@ -222,9 +257,8 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n_, int 
       for (int h = 0; h < 2; h++) {
         const qp_gdouble *colk = L + (size_t)(k + 4 * h + l4) * ld;
         rd[st][h] = Dg[k + 4 * h + l4];
-        ra[st][h][0] = colk[rowp0]; ra[st][h][1] = colk[rowp1];
-#pragma unroll
-        for (int t = 0; t < NTJ; t++) rb[st][h][t] = colk[rowc[t]];
+        qp_load_rows<2>(colk + rowa, ra[st][h]);
+        qp_load_rows<NTJ>(colk + rowb, rb[st][h]);
       }
     };
     auto mma = [&](const int st) QP_ALWAYS_INLINE {
@@ -254,13 +288,13 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n_, int 
   }
 #pragma unroll
   for (int t = 0; t < NTJ; t++) {
-    const int row = (tile0 + t * QP_NW) * 16 + l15;
+    const int row = rowof(t, l15);
     if (row < n) {
 #pragma unroll
       for (int ct = 0; ct < 2; ct++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int col = J + ct * 16 + l4 + 4 * r;
+          const int col = colof(ct, l4 + 4 * r);
           if (col < n && row >= col) L[(size_t)col * ld + row] = acc[t][ct][r];
         }
     }
@@ -574,33 +608,6 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
 #define QP_UNB 32
 #ifndef QP_TQD
 #define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
-#endif
-/* R adjacent rows of one column: 16-byte accesses where R is even (the address is 16-byte aligned:
- * row index and leading dimension are even, slots are 256-byte aligned) */
-#ifdef QPALM_EMU
-template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) { for (int k = 0; k < R; k++) v[k] = p[k]; }
-template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) { for (int k = 0; k < R; k++) p[k] = v[k]; }
-#else
-typedef double qp_double2 __attribute__((ext_vector_type(2)));
-typedef qp_double2 __attribute__((address_space(1))) qp_gdouble2;
-template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) {
-  if (R % 2 == 0) {
-#pragma unroll
-    for (int k = 0; k < R; k += 2) { const qp_double2 t = *(const qp_gdouble2 *)(p + k); v[k] = t.x; v[k + 1] = t.y; }
-  } else {
-#pragma unroll
-    for (int k = 0; k < R; k++) v[k] = p[k];
-  }
-}
-template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) {
-  if (R % 2 == 0) {
-#pragma unroll
-    for (int k = 0; k < R; k += 2) { qp_double2 t; t.x = v[k]; t.y = v[k + 1]; *(qp_gdouble2 *)(p + k) = t; }
-  } else {
-#pragma unroll
-    for (int k = 0; k < R; k++) p[k] = v[k];
-  }
-}
 #endif
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
