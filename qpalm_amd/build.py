@@ -35,6 +35,7 @@ def build_hip(force=False, verbose=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-mllvm", "-enable-ipra=0",
            "-Wno-unused-value", "-o", LIB, os.path.join(CSRC, "qpalm_gfx950.hip")]
+    cmd += os.environ.get("QPALM_EXTRA_DEFS", "").split()  # experiments: e.g. -DQP_UHELP=1
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -60,6 +61,7 @@ def build_emu(force=False, block=128):
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DQP_T=%d" % block,
            "-Wno-unknown-pragmas", os.path.join(EMU_DIR, "qpalm_emu.cpp"), os.path.join(EMU_DIR, "hip_emu.cpp"),
            "-o", EMU_LIB]
+    cmd += os.environ.get("QPALM_EXTRA_DEFS", "").split()
     subprocess.check_call(cmd)
     return EMU_LIB
 

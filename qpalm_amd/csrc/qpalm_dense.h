@@ -21,7 +21,23 @@
 #define QP_WAVE_SYNC() emu_wave_sync()
 #define QP_SCHED_BARRIER() do { } while (0)
 #define QP_SETPRIO(p) do { } while (0)
+/* LDS flags between wavefronts of one workgroup (helper wave of the update sweep) */
+#define QP_FLAG_STORE(p, v) (*(volatile int *)(p) = (v))
+#define QP_FLAG_LOAD(p) (*(volatile int *)(p))
+#define QP_SPIN_PAUSE() emu::yield_fiber()
 #else
+/* The flags and the data they guard both live in LDS, and the LDS unit executes the DS instructions
+ * of a wavefront in program order, so relaxed accesses plus a compiler barrier are enough.  (Acquire /
+ * release at workgroup scope would also drain vmcnt, i.e. the prefetch queue of L columns.) */
+#define QP_FLAG_STORE(p, v) do { asm volatile("" ::: "memory"); __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); } while (0)
+static __device__ __forceinline__ int qp_flag_load_(int __attribute__((address_space(3))) *p) {
+  asm volatile("" ::: "memory");
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+#define QP_FLAG_LOAD(p) qp_flag_load_((p))
+#define QP_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
 #define QP_SETPRIO(p) __builtin_amdgcn_s_setprio(p) /* issue priority of a wavefront on its SIMD */
 /* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
 #define QP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -606,17 +622,21 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
  * arithmetic per entry is the same sequence of FMAs as without look-ahead.
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
+#ifndef QP_UHELP
+#define QP_UHELP 0 /* 1: wavefront 1 applies the look-ahead rows column by column behind the panel wave */
+#endif
 #ifndef QP_TQD
 #define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
 #endif
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
   double Ld[2][QP_UNB][QP_UNB + 1];
-  double Wd[2][QP_UNB][K + 1]; /* running w of the rows of a block, handed from their owners to wavefront 0 */
+  double Wd[QP_UHELP ? 3 : 2][QP_UNB][K + 1]; /* running w of the rows of block b: owners -> (helper wave ->) panel wave */
   double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
   double dd[2][QP_UNB];
+  int prog[2];                 /* helper variant: columns of table [parity] published so far */
 };
 
 #ifdef QPALM_EMU
@@ -695,11 +715,13 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) {
         const int i = tid * RPT + rr;
-        if (i >= J0 && i < J0 + jb0) {
+        if (i >= J0 && i < J0 + (QP_UHELP ? 2 * NB : jb0) && i < n) { /* block 0 (helper variant: blocks 0 and 1) */
+          const int bs = (i - J0) / NB;
 #pragma unroll
-          for (int r = 0; r < K; r++) U.Wd[0][i - J0][r] = w[rr][r];
+          for (int r = 0; r < K; r++) U.Wd[bs][(i - J0) % NB][r] = w[rr][r];
         }
       }
+      if (tid < 2) U.prog[tid] = 0;
       for (int e = tid; e < jb0 * jb0; e += QP_T) {
         const int c1 = e / jb0, c = e % jb0;
         if (c > c1) U.Ld[0][c][c1] = L[(size_t)(J0 + c1) * ld + (J0 + c)];
@@ -719,15 +741,21 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       const int jb = (n - J < NB) ? (n - J) : NB;
       const int jbn = (n - Jn < NB) ? ((n - Jn > 0) ? (n - Jn) : 0) : NB; /* 0 when block s is the last one */
       const int cur = s & 1, prv = cur ^ 1;
-      const bool own_live0 = (64 * RPT - 1 >= Jn); /* wavefront 0 still owns rows below block s */
+      const long long tph0 = QP_CLOCK();
+      /* owners work on rows from Jo on and hand block Jo over: the block after this one, or (helper
+       * variant) the one after that */
+      const int Jo = QP_UHELP ? Jn + NB : Jn;
+      const int jbo = (n - Jo < NB) ? ((n - Jo > 0) ? (n - Jo) : 0) : NB;
+      const int wslot = QP_UHELP ? (s % 3) : cur, hslot = QP_UHELP ? ((s + 2) % 3) : prv;
+      const bool own_live0 = (64 * RPT - 1 >= Jo); /* wavefront 0 still owns rows the owners work on */
       if (wid == 0) {
         /* ===== panel wave ===================================================================== */
         const long long tp0 = QP_CLOCK();
         QP_SETPRIO(3); /* the serial chain of the sweep goes first on its SIMD */
         double wrow[K];
 #pragma unroll
-        for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[cur][lane][r] : 0.0;
-        if (s > 0) {
+        for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[wslot][lane][r] : 0.0;
+        if (!QP_UHELP && s > 0) {
           /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
            * deeper queue (one row per lane: registers to spare, and this wave is the critical path) */
           constexpr int QD = 8;
@@ -807,6 +835,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             if (ln == c1) dreg = dfin;
           }
           QP_WAVE_SYNC();
+          if (QP_UHELP && ln == 0) QP_FLAG_STORE(&U.prog[cur], c1 + 1); /* column c1 of table s is published */
           /* rows of the block: lane = row.  Rows <= c1 are finished, their registers may be
            * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
           {
@@ -847,7 +876,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         const long long tt0 = QP_CLOCK();
         bool any = false;
 #pragma unroll
-        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jn && i < n); }
+        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jo && i < n); }
         if (s > 0 && any) {
           /* One column per iteration.  Branch-free body: rows that are not below the block read/write
            * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
@@ -858,7 +887,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * one address and one liveness per thread.  Rows n..ld-1 are padding of the panel (ld is a
            * multiple of 8): they are carried along (w = 0 there, nobody reads them). */
           const int i0 = tid * RPT;
-          const bool ok = (i0 >= Jn && i0 < ld);
+          const bool ok = (i0 >= Jo && i0 < ld);
           qp_gdouble *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
           const size_t cstride = ok ? (size_t)ld : 0;
           double q[QD][RPT];
@@ -905,9 +934,9 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
           const int i = tid * RPT + rr;
-          if (i >= Jn && i < Jn + jbn) {
+          if (i >= Jo && i < Jo + jbo) {
 #pragma unroll
-            for (int r = 0; r < K; r++) U.Wd[prv][i - Jn][r] = w[rr][r];
+            for (int r = 0; r < K; r++) U.Wd[hslot][i - Jo][r] = w[rr][r];
           }
         }
         if (wid == 0) {
@@ -925,6 +954,80 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           if (c > c1) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
         }
         if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
+      }
+      if (QP_UHELP && wid == 1 && jbn > 0) {
+        /* ===== helper wave: the 32 rows of block s+1 (lane = row, handed over in phase s-1 with
+         * tables < s-1 applied) get table s-1 and then table s, column by column right behind the
+         * panel wave (LDS column counter, no barrier): ready when the phase ends. ================ */
+        const long long th0 = QP_CLOCK();
+        if (lane == 0) tdbg[14] += th0 - tph0; /* helper start delay */
+        QP_SETPRIO(3);
+        /* this wavefront's own running w leaves the registers for the duration (HBM/L2 stash; the LDS
+         * stash belongs to wavefront 0), only while its own rows are still live */
+        const bool own_live1 = (64 * RPT * 2 - 1 >= Jo);
+        qp_gdouble *hst = dummy + QPG_DUMMY;
+        if (own_live1) {
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+            for (int r = 0; r < K; r++) hst[(rr * K + r) * 64 + lane] = w[rr][r];
+        }
+        const int hs = (s + 1) % 3;
+        double wrow[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) wrow[r] = (lane < jbn) ? U.Wd[hs][lane][r] : 0.0;
+        constexpr int QD = 8;
+        const size_t cstride = (lane < jbn) ? (size_t)ld : 0;
+#pragma unroll 1
+        for (int pass = (s > 0) ? 0 : 1; pass < 2; pass++) { /* 0: table s-1 (complete), 1: table s (growing) */
+          const int tb = pass ? cur : prv;
+          qp_gdouble *rowp = (lane < jbn) ? (L + (size_t)(pass ? J : Jp) * ld + Jn + lane) : (dummy + lane);
+          double q[QD];
+#pragma unroll
+          for (int cc = 0; cc < QD; cc++) q[cc] = rowp[(size_t)cc * cstride];
+          int avail = pass ? 0 : NB; /* columns of the table known to be published */
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
+#pragma unroll
+            for (int u = 0; u < QD; u++) {
+              const int c1 = c0 + u;
+              while (avail <= c1) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= c1) QP_SPIN_PAUSE(); }
+              double l = q[u];
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+#pragma unroll
+              for (int rb = 0; rb < K; rb += 8) {
+                if (rb >= kk) break;
+                double cw[8], cg[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[tb][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[tb][c1][rb + r][1] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                  if (rb + r < K) {
+                    wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
+                    l = QP_FMA(cg[r], wrow[rb + r], l);
+                  }
+                }
+              }
+              rowp[(size_t)c1 * cstride] = l;
+              QP_SCHED_BARRIER();
+              q[u] = rowp[(size_t)cpre * cstride];
+              QP_SCHED_BARRIER();
+            }
+          };
+          group(0);
+#pragma unroll 1
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+        }
+        if (lane < jbn) {
+#pragma unroll
+          for (int r = 0; r < K; r++) U.Wd[hs][lane][r] = wrow[r];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+          for (int r = 0; r < K; r++) w[rr][r] = own_live1 ? hst[(rr * K + r) * 64 + lane] : 0.0;
+        QP_SETPRIO(0);
+        QP_WAVE_SYNC(); /* every lane is past its flag reads before the counter is re-armed */
+        if (lane == 0) { U.prog[cur] = 0; tdbg[13] += QP_CLOCK() - th0; }
       }
       __syncthreads();
     }

@@ -85,5 +85,6 @@ typedef struct {
 
 #define QPG_KMAX 16
 #define QPG_DUMMY 4096 /* doubles per slot that masked-off rows load from / store to */
+#define QPG_HSTASH 4096 /* doubles per slot where the helper wave of the update sweep parks its own running w */
 
 #endif
