@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "2048")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "4096")),
                     help="QPs per GPU (512 resident factor slots = workgroups; the rest queue up behind them)")
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--m", type=int, default=2000)
