@@ -1,65 +1,136 @@
 #!/usr/bin/env python3
-"""bench.py -- QP solves/sec on batched random QPs (n=1000, m=2000, ~1 % dense A), BASELINE.json's metric.
+"""bench.py -- QP solves/sec on batched QPs, BASELINE.json's metric.
 
-One "step" = one pass of the hot path over one batch: every QP of the (HBM-resident, already
-scaled) batch is cold-started (qpalm_warm_start(NULL, NULL)) and solved to eps 1e-6 by the persistent
-gfx950 kernel; with N > 1 ranks every rank owns its own shard of B QPs (weak scaling) and the
-solutions are gathered to rank 0 over RCCL inside the timed region.
+Workloads (--workload):
+  random-1000 (default, BASELINE.json configs[1]): n=1000, m=2000, ~1 % dense A, cold start, eps 1e-6.
+  mpc-160     (configs[2]): n=160, m=270 non-condensed MPC QPs (T=10, nx=10, nu=5), perturbed initial states,
+              update_bounds + warm start between steps (simulations/randomMPCsequential.m:158-177).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_solve): algorithmic bytes of
-SURVEY.md section 8d, counted from the device-side work counters, divided by the kernel's HIP-event
-duration.  `cpu_baseline` times the CPU oracle ("port") on a bounded sample of the same QPs.
+One "step" = one pass of the hot path over one batch: every QP of the (HBM-resident, already scaled) batch is
+(re)started and solved by the persistent gfx950 kernel.  With N > 1 ranks every rank owns its own shard of B QPs
+(weak scaling, no data-path collective) and solution.x, solution.y and the QPALMInfo records are gathered to rank 0
+over RCCL inside the timed region.
+
+`python bench.py --gpus N` without a torch.distributed environment starts N ranks itself (one child process per
+GPU, started BEFORE this process imports torch or touches HIP); under torchrun the environment is used as is.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_solve): algorithmic bytes of SURVEY.md
+section 8d, counted from device-side work counters, divided by the kernel's HIP-event duration; fractions are quoted
+against the 8 TB/s spec and against a copy kernel measured in the same run.  `cpu_baseline` times the CPU oracle
+("port") on a bounded sample of the same QPs.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
-PMC_FILE = os.path.join(ROOT, "profiles", "r01", "k_solve_pmc_traffic.json")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+RESIDENT_WORKGROUPS = 512  # 2 workgroups per CU x 256 CUs (QP_WAVES_PER_SIMD = 4)
 
 
-def pmc_traffic(batch, n, m):
-    """HBM bytes per k_solve launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected in
-    separate runs of this very command, corrected as MI355X_MICROARCH.md prescribes); None when no pass matches."""
-    try:
-        with open(PMC_FILE) as f:
-            d = json.load(f)
-        if d["batch"] == batch and d["n"] == n and d["m"] == m:
-            return float(d["traffic_bytes_per_launch"])
-    except Exception:
-        pass
-    return None
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="random-1000", choices=("random-1000", "mpc-160"))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "4096")),
+                    help="QPs per GPU (512 resident factor slots = workgroups; the rest queue up behind them)")
+    ap.add_argument("--n", type=int, default=0, help="random workload: number of variables (default 1000)")
+    ap.add_argument("--m", type=int, default=0, help="random workload: number of constraints (default 2 n)")
+    ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
+    ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
+    ap.add_argument("--traffic-json", default=None,
+                    help="PMC summary written by tools/round_artifacts.sh for THIS build and command (stamped with the git SHA); "
+                         "without it roofline.traffic is null")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a torch.distributed environment
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Start N fresh child processes (one per GPU) before anything here has initialised the GPU; relay rank 0's
+    JSON line; non-zero exit if any rank fails.  Never re-execs a GPU-initialised process."""
+    import socket
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or b"").decode(errors="replace").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if any(codes) or line is None:
+        sys.stderr.write("bench.py: rank exit codes %s%s\n" % (codes, "" if line else " (no JSON line from rank 0)"))
+        return 1 if not any(codes) else max(abs(c) for c in codes) or 1
+    print(line)
+    return 0
 
-def algorithmic_bytes(n, m, nnzA, nnzQ, stats, iters):
-    """SURVEY.md section 8d byte model, per QP (fp64 = 8 B, int32 indices = 4 B)."""
-    nnzL = n * (n + 1) // 2
-    b_solve = 2 * nnzL * 8 + 8 * n + 16 * n
+
+# ---------------------------------------------------------------------------------------------------------------
+# byte model, per QP; fp64 = 8 B, int32 indices = 4 B
+# ---------------------------------------------------------------------------------------------------------------
+def byte_model(n, m, nnzA, nnzQ):
+    nnzL = n * (n + 1) // 2                     # dense-triangle storage of the factor (natural ordering, F5)
+    b_solve = 2 * nnzL * 8 + 8 * n + 16 * n     # L twice + D + rhs/d
     b_spmv_A = nnzA * 12 + 4 * (n + 1) + 8 * (m + n)
     b_spmv_Q = nnzQ * 12 + 4 * (n + 1) + 16 * n
     b_vec = 8 * (22 * m + 18 * n) + 2 * (2 * m * 12)
-    b_newton = b_solve + 2 * b_spmv_A + b_spmv_Q + b_vec
-    b_outer = b_spmv_A + b_vec
-    b_refactor = nnzL * 8 + (nnzQ + nnzA) * 12
-    b_sweep = 2 * 8 * nnzL  # upper bound of section 8d: a sweep touches L[:, j0:] once, read + write
-    n_newton = stats["n_solve"]
-    total = n_newton * b_newton + max(iters - n_newton, 0) * b_outer
-    total += (stats["n_refactor"] + stats["n_factor_Q"]) * b_refactor + stats["n_sweeps"] * b_sweep
-    return total, dict(b_solve=b_solve, b_newton=b_newton, b_sweep=b_sweep, b_refactor=b_refactor)
+    return dict(b_solve=b_solve, b_spmv_vec_newton=2 * b_spmv_A + b_spmv_Q + b_vec, b_spmv_vec_outer=b_spmv_A + b_vec,
+                b_refactor=nnzL * 8 + (nnzQ + nnzA) * 12, b_sweep_entry=16)   # a touched entry of L is read and written once
 
 
-def cpu_baseline(problems, settings_kw, budget_s=20.0):
-    """Oracle ("port") on host cores, one QP per thread; bounded sample."""
-    import subprocess
+def phase_bytes(model, st, iters):
+    """algorithmic bytes of one QP's solve by phase, from the device-side work counters"""
+    n_newton = int(st.n_solve)
+    return {
+        "solve": n_newton * model["b_solve"],
+        "spmv_vectors": n_newton * model["b_spmv_vec_newton"] + max(iters - n_newton, 0) * model["b_spmv_vec_outer"],
+        "factor": (int(st.n_refactor) + int(st.n_factor_Q)) * model["b_refactor"],
+        "update": int(st.sweep_entries) * model["b_sweep_entry"],   # sum over sweeps of nnz(L[:, J0:]), counted by the sweep itself
+    }
+
+
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cholmod_probe():
+    """the genuine CHOLMOD path is the CPU baseline only if the box has SuiteSparse."""
+    import ctypes.util
+    lib = ctypes.util.find_library("cholmod")
+    hdr = [p for p in ("/usr/include/suitesparse/cholmod.h", "/usr/include/cholmod.h", "/usr/local/include/cholmod.h",
+                       "/opt/conda/include/cholmod.h") if os.path.exists(p)]
+    return {"libcholmod": lib, "cholmod_h": hdr[0] if hdr else None}
+
+
+def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
+    """Oracle ("port") on host cores, one QP per thread; bounded sample.  Reported next to the GPU figure, not a target."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
     cores = max(1, min(os.cpu_count() or 1, 64))
@@ -73,86 +144,141 @@ def cpu_baseline(problems, settings_kw, budget_s=20.0):
         libpath = None
 
     def one(p):
-        o = ob.OracleQP(*p.args(), settings=ob.default_settings(**settings_kw), libpath=libpath)
         t0 = time.perf_counter()
+        o = ob.OracleQP(*p.args(), settings=ob.default_settings(**settings_kw), libpath=libpath)   # setup: copies + Ruiz scaling
+        t1 = time.perf_counter()
         o.solve()
-        dt = time.perf_counter() - t0
+        t2 = time.perf_counter()
         st = o.status_val
         o.cleanup()
-        return dt, st
+        return t2 - t1, t2 - t0, st
 
-    t_probe, _ = one(problems[0])
-    nsample = int(max(cores, min(len(problems), cores * max(1.0, budget_s / max(t_probe, 1e-3)) / 1.0)))
-    nsample = min(nsample, len(problems), 4 * cores)
+    t_probe, _, _ = one(problems[0])
+    nsample = int(max(cores, min(len(problems), cores * max(1.0, budget_s / max(t_probe, 1e-3)))))
+    nsample = min(nsample, len(problems), 64 * cores)
     sample = problems[:nsample]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         res = list(ex.map(one, sample))
     wall = time.perf_counter() - t0
-    assert all(s == 1 for _, s in res)
-    return {"value": len(sample) / wall, "unit": "QP/s", "cores": cores, "kind": "port",
-            "sample": "%d of the batch's random-1000 QPs, solve phase only (eps 1e-6), one QP per thread, "
-                      "oracle/qpalm_oracle.c built -O3 -march=native; single-QP time %.3f s" % (len(sample), t_probe)}
+    assert all(s == 1 for _, _, s in res)
+    probe = cholmod_probe()
+    return {"value": len(sample) / wall, "unit": "QP/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_string(),
+            "setup_plus_solve_s_per_qp": sum(t for _, t, _ in res) / len(res), "solve_s_per_qp": sum(t for t, _, _ in res) / len(res),
+            "cholmod_probe": probe,
+            "sample": "%d of the batch's %s QPs, setup + solve timed as info.run_time does (eps 1e-6), one QP per thread, "
+                      "oracle/qpalm_oracle.c (dense LDL', scalar rank-1 sweeps) built -O3 -march=native; single-QP solve %.4f s; "
+                      "no system CHOLMOD on the box (probe in cholmod_probe), so this is the restatement, not CHOLMOD"
+                      % (len(sample), workload, t_probe)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "4096")),
-                    help="QPs per GPU (512 resident factor slots = workgroups; the rest queue up behind them)")
-    ap.add_argument("--n", type=int, default=1000)
-    ap.add_argument("--m", type=int, default=2000)
-    ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
-    ap.add_argument("--dbg-flags", type=int, default=0, help="timing experiments only (results wrong)")
-    args = ap.parse_args()
+def kkt_spot_check(probs, xs, ys, idx):
+    """numpy KKT residuals of a few QPs of the timed batch on the unscaled data (a broken build must not post a number)"""
+    import numpy as np
+    import scipy.sparse as sp
+    worst = 0.0
+    for k in idx:
+        p = probs[k]
+        A = sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n))
+        Ql = sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(p.n, p.n))
+        Q = Ql + sp.tril(Ql, -1).T
+        x, y = xs[k], ys[k]
+        ax = A @ x
+        prim = np.max(np.maximum(p.bmin - ax, 0) + np.maximum(ax - p.bmax, 0)) / max(1.0, np.max(np.abs(ax)))
+        Qx, Aty = Q @ x, A.T @ y
+        dual = np.max(np.abs(Qx + p.q + Aty)) / max(1.0, np.max(np.abs(Qx)), np.max(np.abs(p.q)), np.max(np.abs(Aty)))
+        worst = max(worst, prim, dual)
+    return worst
 
+
+# ---------------------------------------------------------------------------------------------------------------
+def worker(args):
+    import numpy as np
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        return 2
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d: no HIP device %d visible (this benchmark has no CPU path)\n" % (rank, local))
+        return 3
     dist = None
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
 
-    from qpalm_amd.problems import random_qp
+    from qpalm_amd.problems import random_mpc_qp, random_qp
     from qpalm_amd.solver import Context, QpalmBatch
-    ctx = Context(local)
+    ctx = Context(local, lib_path=args.lib)
     ctx.set_option("update_rank_threshold", args.rank_threshold)
-    if args.dbg_flags:
-        ctx.set_option("dbg_flags", args.dbg_flags)
     if args.max_slots:
         ctx.set_option("max_slots", args.max_slots)
-    B, n, m = args.batch, args.n, args.m
+    B = args.batch
     settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
-    dens_A = 0.01 if n >= 400 else max(0.01, 4.0 / n)
-    dens_M = 0.005 if n >= 400 else max(0.005, 2.0 / n)
-    probs = [random_qp(n, m, seed=1000 + rank * B + k, density_A=dens_A, density_M=dens_M) for k in range(B)]
+    rng = np.random.default_rng(12345 + rank)
+    if args.workload == "random-1000":
+        n = args.n or 1000
+        m = args.m or 2 * n
+        dens_A = 0.01 if n >= 400 else max(0.01, 4.0 / n)
+        dens_M = 0.005 if n >= 400 else max(0.005, 2.0 / n)
+        probs = [random_qp(n, m, seed=1000 + rank * B + k, density_A=dens_A, density_M=dens_M) for k in range(B)]
+        wl = "random-%d: batch of %d QPs per GPU, n=%d m=%d nnz(A)~%d nnz(tril Q)~%d, eps 1e-6, scaling 10, cold start" % (
+            n, B, n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1]))
+    else:
+        # one plant per 64 QPs, every QP its own initial state; the steps move the initial state (bounds of the x_0 rows)
+        nx, nu, T = 10, 5, 10
+        plants = {}
+        probs = []
+        for k in range(B):
+            seed = rank * 100003 + k // 64
+            if seed not in plants:
+                plants[seed] = random_mpc_qp(T=T, nx=nx, nu=nu, seed=seed)
+            base = plants[seed]
+            x0 = 2.0 * (2 * rng.random(nx) - 1)
+            bmin, bmax = base.bmin.copy(), base.bmax.copy()
+            bmin[:nx] = x0
+            bmax[:nx] = x0
+            probs.append(type(base)(base.n, base.m, base.Qp, base.Qi, base.Qx, base.Ap, base.Ai, base.Ax, base.q, bmin, bmax))
+        n, m = probs[0].n, probs[0].m
+        wl = "mpc-160: batch of %d MPC QPs per GPU (T=10, nx=10, nu=5: n=%d m=%d nnz(A)=%d), eps 1e-6, scaling 10; every step moves " \
+             "the initial states (update_bounds) and warm-starts from the previous solution" % (B, n, m, int(probs[0].Ap[-1]))
     bt = QpalmBatch(ctx, probs, ctx.default_settings(**settings_kw))   # upload + Ruiz scaling: not timed
+    bmin_all = np.stack([p.bmin for p in probs])
+    bmax_all = np.stack([p.bmax for p in probs])
+    state = {"x": None, "y": None}
 
-    def gather_solutions():
+    def gather_results():
         if world == 1:
             return
-        from qpalm_amd.dist import device_view
-        tx = device_view(bt, "solution_x", (B, n), "cuda:%d" % local)   # zero-copy views of the HBM arrays
-        ty = device_view(bt, "solution_y", (B, m), "cuda:%d" % local)
-        gx = [torch.empty_like(tx) for _ in range(world)] if rank == 0 else None
-        gy = [torch.empty_like(ty) for _ in range(world)] if rank == 0 else None
-        dist.gather(tx, gx, dst=0)
-        dist.gather(ty, gy, dst=0)
+        from qpalm_amd.dist import device_view, info_matrix
+        dev = "cuda:%d" % local
+        tx = device_view(bt, "solution_x", (B, n), dev)   # zero-copy views of the HBM arrays
+        ty = device_view(bt, "solution_y", (B, m), dev)
+        ti = torch.from_numpy(info_matrix(bt)).to(dev)     # QPALMInfo records (include/types.h:76-95), one D2H copy
+        for t in (tx, ty, ti):
+            g = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+            dist.gather(t, g, dst=0)
 
     def step():
-        bt.warm_start(None, None)
+        if args.workload == "mpc-160":
+            if state["x"] is not None:   # the plant moved: new initial state, warm start from the previous solution
+                x0 = bmin_all[:, :10] + 0.1 * rng.standard_normal((B, 10))
+                bmin_all[:, :10] = x0
+                bmax_all[:, :10] = x0
+                bt.update_bounds(bmin_all, bmax_all)
+                bt.warm_start(state["x"], state["y"])
+            else:
+                bt.warm_start(None, None)
+        else:
+            bt.warm_start(None, None)
         bt.solve()
-        gather_solutions()
+        if args.workload == "mpc-160":
+            state["x"], state["y"] = bt.solution()
+        gather_results()
 
     def barrier():
         if world > 1:
@@ -174,56 +300,101 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # parity summary + work counters of the last step
-    statuses = bt.statuses()
-    iters = np.array([int(bt.info(b).iter) for b in range(B)])
-    stats = [bt.stats(b) for b in range(B)]
-    keys = ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve")
-    tot_bytes = 0
+    # ---- checks + accounting of the last step (outside the timed region) ------------------------------------
+    infos, stats = bt.infos(), bt.stats_all()
+    statuses = np.array([int(i.status_val) for i in infos])
+    iters = np.array([int(i.iter) for i in infos])
+    n_bad = int(np.sum(statuses != 1))
+    xs, ys = bt.solution()
+    kkt = kkt_spot_check(probs, xs, ys, sorted({0, B // 3, B // 2, B - 1}))
+    ok = (n_bad == 0) and (kkt <= 1e-4)
+    tot = {"solve": 0, "spmv_vectors": 0, "factor": 0, "update": 0}
     for b in range(B):
-        sd = {k: int(getattr(stats[b], k)) for k in keys}
-        tb, parts = algorithmic_bytes(n, m, int(probs[b].Ap[-1]), int(probs[b].Qp[-1]), sd, int(iters[b]))
-        tot_bytes += tb
+        model = byte_model(n, m, int(probs[b].Ap[-1]), int(probs[b].Qp[-1]))
+        pb = phase_bytes(model, stats[b], int(iters[b]))
+        for k in tot:
+            tot[k] += pb[k]
+    tot_bytes = sum(tot.values())
     kms = float(np.mean(kernel_ms))
     achieved = tot_bytes / (kms * 1e-3) / 1e9
-    phase = {k: float(np.mean([getattr(s, k) for s in stats])) for k in ("ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")}
-    phase["dbg"] = [float(np.mean([s.ms_dbg[k] for s in stats])) for k in range(16)]
-
-    out = None
+    mean = lambda f: float(np.mean([f(s) for s in stats]))
+    phase_ms = {"total": mean(lambda s: s.ms_total), "factor": mean(lambda s: s.ms_factor), "update": mean(lambda s: s.ms_update),
+                "solve": mean(lambda s: s.ms_solve), "linesearch": mean(lambda s: s.ms_linesearch), "residuals": mean(lambda s: s.ms_dbg[12])}
+    phase_ms["dbg"] = [mean(lambda s, k=k: s.ms_dbg[k]) for k in range(16)]
+    conc = min(B, RESIDENT_WORKGROUPS if not args.max_slots else args.max_slots)
+    # aggregate GB/s of a phase = bytes of all QPs / (time the phase occupies one of `conc` concurrent workgroups)
+    def phase_gbs(nbytes, ms_per_qp):
+        return nbytes / (max(ms_per_qp, 1e-9) * 1e-3 * B / conc) / 1e9
+    phases = {
+        "solve": {"bytes": tot["solve"], "ms_per_qp": phase_ms["solve"], "GBps": phase_gbs(tot["solve"], phase_ms["solve"])},
+        "update": {"bytes": tot["update"], "ms_per_qp": phase_ms["update"], "GBps": phase_gbs(tot["update"], phase_ms["update"])},
+        "factor": {"bytes": tot["factor"], "ms_per_qp": phase_ms["factor"], "GBps": phase_gbs(tot["factor"], phase_ms["factor"]),
+                   "flop": float(sum((int(s.n_refactor) + int(s.n_factor_Q)) for s in stats)) * n ** 3 / 3.0,
+                   "reread_bytes": float(sum(int(s.factor_reread_entries) for s in stats)) * 8},
+        "spmv_vectors": {"bytes": tot["spmv_vectors"], "ms_per_qp": phase_ms["linesearch"] + phase_ms["residuals"],
+                         "GBps": phase_gbs(tot["spmv_vectors"], phase_ms["linesearch"] + phase_ms["residuals"])},
+    }
+    phases["factor"]["TFLOPs"] = phases["factor"]["flop"] / (max(phase_ms["factor"], 1e-9) * 1e-3 * B / conc) / 1e12
+    rc = 0
     if rank == 0:
-        # stand-alone LDL^T solve kernel (the "HBM GB/s on LDL" half of the metric)
-        nsl = min(B, 512)
-        ms_ldl = bt.ldlsolve_all(reps=4)
-        ldl_bytes = nsl * parts["b_solve"]
+        copy_gbs = ctx.hbm_copy_gbs(1 << 30, 5)             # attainable ceiling on this box (read + write)
+        model0 = byte_model(n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1]))
+        nsl = min(B, RESIDENT_WORKGROUPS)
+        ms_ldl = bt.ldlsolve_all(reps=4)                    # stand-alone LDL' solve kernel ("HBM GB/s on LDL")
+        ldl_bytes = nsl * model0["b_solve"]
+        traffic = None
+        if args.traffic_json and world == 1:
+            try:
+                with open(args.traffic_json) as f:
+                    traffic = float(json.load(f)["traffic_bytes_per_launch"])
+            except Exception:
+                traffic = None
         out = {
-            "metric": "QP solves/sec (batched random n=%d,m=%d)" % (n, m),
+            "metric": "QP solves/sec (batched %s)" % ("random n=%d,m=%d" % (n, m) if args.workload == "random-1000" else "MPC n=%d,m=%d, warm-started sequence" % (n, m)),
             "value": world * B * args.steps / elapsed, "unit": "QP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "random-%d: batch of %d QPs per GPU, n=%d m=%d nnz(A)~%d nnz(tril Q)~%d, eps 1e-6, "
-                                   "scaling 10, cold start" % (n, B, n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1])),
-                       "batch_per_gpu": B, "parallelism": "batch-shard x%d" % world,
+            "config": {"workload": wl, "batch_per_gpu": B, "parallelism": "batch-shard x%d" % world,
                        "update_rank_threshold": args.rank_threshold},
             "roofline": {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(B, n, m) if world == 1 else None, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes},
+                         "traffic": traffic, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes,
+                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
+                         "bytes_note": "update bytes = 16 B x entries of L[:, J0:] actually swept (device counter), not the 8d upper bound",
+                         "phases": phases},
             "ldl_solve": {"kernel": "k_ldlsolve_all", "qps": nsl, "ms": ms_ldl, "bytes": ldl_bytes,
                           "achieved": ldl_bytes / (ms_ldl * 1e-3) / 1e9, "unit": "GB/s",
-                          "frac": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "solve_stats": {"all_solved": bool(np.all(statuses == 1)), "iter_mean": float(iters.mean()), "iter_max": int(iters.max()),
-                            "per_qp_mean": {k: float(np.mean([getattr(s, k) for s in stats])) for k in keys},
-                            "phase_ms_per_qp": phase},
+                          "frac": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "frac_of_measured_copy": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / copy_gbs},
+            "solve_stats": {"all_solved": n_bad == 0, "kkt_spot_check_worst_rel": kkt,
+                            "iter_mean": float(iters.mean()), "iter_max": int(iters.max()),
+                            "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve", "sweep_entries")},
+                            "phase_ms_per_qp": phase_ms},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(probs, settings_kw)
+            out["cpu_baseline"] = cpu_baseline(probs, settings_kw, args.workload)
         else:
             out["cpu_baseline"] = None
+        if not ok:
+            sys.stderr.write("bench.py: INVALID RUN: %d QPs not solved, KKT spot check %.3e\n" % (n_bad, kkt))
+            out["invalid"] = "%d QPs not solved, KKT spot check %.3e" % (n_bad, kkt)
         print(json.dumps(out))
+    if not ok:
+        rc = 4
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)      # before torch / HIP are touched in this process
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -111,6 +111,8 @@ typedef struct {
                            factor: 3 form, 4 panel gemm, 5 block, 6 panel solve;
                            solve: 8 forward block, 9 forward rows below, 10 backward dots, 11 backward block; 12 SpMV+residuals;
                            line search: 13 SpMVs, 14 breakpoints + compaction, 15 sort (the scan is the rest) */
+  qpg_int sweep_entries;         /* entries of L the rank-update sweeps touched (each read and written once): sum of nnz(L[:, J0:]) */
+  qpg_int factor_reread_entries; /* entries of L re-read by the panel updates of the factorisations (beyond the compulsory write) */
 } QPGStats;
 
 typedef struct qpg_ctx qpg_ctx;
@@ -139,6 +141,7 @@ int  qpg_batch_setup(qpg_batch *bt);                               /* upload + R
 int  qpg_batch_warm_start(qpg_batch *bt, const qpg_float *x, const qpg_float *y); /* [B][n], [B][m] or NULL */
 int  qpg_batch_solve(qpg_batch *bt);                               /* run every QP to termination */
 int  qpg_batch_iterate(qpg_batch *bt, qpg_int k);                  /* at most k more loop iterations each */
+int  qpg_batch_begin_solve(qpg_batch *bt);                         /* start of a qpalm_solve driven by qpg_batch_iterate: finished QPs start over */
 int  qpg_batch_last_solve_ms(qpg_batch *bt, float *ms);            /* HIP-event time of the last solve/iterate launch */
 int  qpg_batch_num_unfinished(qpg_batch *bt, qpg_int *count);
 int  qpg_batch_update_settings(qpg_batch *bt, const QPGSettings *s);
@@ -146,6 +149,8 @@ int  qpg_batch_update_bounds(qpg_batch *bt, const qpg_float *bmin, const qpg_flo
 int  qpg_batch_update_q(qpg_batch *bt, const qpg_float *q);                              /* [B][n] */
 int  qpg_batch_get_info(qpg_batch *bt, qpg_int idx, QPGInfo *out);
 int  qpg_batch_get_stats(qpg_batch *bt, qpg_int idx, QPGStats *out);
+int  qpg_batch_get_info_all(qpg_batch *bt, QPGInfo *out /* [B] */);   /* QPALMInfo of every QP (what the multi-GPU gather sends) */
+int  qpg_batch_get_stats_all(qpg_batch *bt, QPGStats *out /* [B] */);
 int  qpg_batch_get_solution(qpg_batch *bt, qpg_float *x, qpg_float *y);                  /* [B][n], [B][m] */
 int  qpg_batch_get_vector(qpg_batch *bt, const char *name, qpg_int idx, qpg_float *out, qpg_int len);
 int  qpg_batch_set_vector(qpg_batch *bt, const char *name, qpg_int idx, const qpg_float *in, qpg_int len);
@@ -178,6 +183,9 @@ int qpg_exact_linesearch(qpg_batch *bt, qpg_int idx, qpg_float *tau);
 /* batched LDL^T solve of the current factors with right-hand side dphi (the kernel the metric's
  * "HBM GB/s on LDL" refers to): every QP of the batch, `reps` times, for benchmarking. */
 int qpg_batch_ldlsolve_all(qpg_batch *bt, qpg_int reps, float *ms_per_rep);
+/* attainable HBM bandwidth of this device, measured with a plain copy kernel (best of `reps` copies of `bytes` bytes;
+ * read + write counted): the yardstick quoted next to the 8 TB/s spec figure */
+int qpg_ctx_hbm_copy_gbs(qpg_ctx *ctx, size_t bytes, qpg_int reps, float *gbs);
 
 #ifdef __cplusplus
 }

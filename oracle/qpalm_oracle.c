@@ -1230,6 +1230,7 @@ void oq_set_scalar(oq_workspace *w, const char *name, oq_float v) {
   else if (!strcmp(name, "reset_newton")) w->reset_newton = (int)v;
   else if (!strcmp(name, "eps_abs_in")) w->eps_abs_in = v;
   else if (!strcmp(name, "eps_rel_in")) w->eps_rel_in = v;
+  else if (!strcmp(name, "nb_sigma_changed")) w->nb_sigma_changed = (oq_int)v; /* op-level tests of ldlupdate_sigma_changed */
 }
 oq_int oq_get_counter(const oq_workspace *w, const char *name) {
   if (!strcmp(name, "n_refactor")) return w->n_refactor;

@@ -48,7 +48,7 @@ class Stats(C.Structure):
                                      "n_boost_gamma", "nb_active", "nb_enter", "nb_leave", "last_kind", "last_fact")] + \
                [(k, c_float) for k in ("gamma", "tau", "eta", "beta", "eps_pri", "eps_dua", "eps_dua_in", "sc_c",
                                        "ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")] + \
-               [("ms_dbg", c_float * 16)]
+               [("ms_dbg", c_float * 16), ("sweep_entries", c_int), ("factor_reread_entries", c_int)]
 
 
 class QpgError(RuntimeError):
@@ -61,8 +61,7 @@ _LIBS = {}
 
 
 def load(path=None):
-    # QPALM_GFX950_LIB: A/B benchmarking of two HIP builds on one box (never a fallback: still a HIP library)
-    path = path or os.environ.get("QPALM_GFX950_LIB") or LIB_PATH
+    path = path or LIB_PATH
     if path in _LIBS:
         return _LIBS[path]
     if not os.path.exists(path):
@@ -79,7 +78,7 @@ def load(path=None):
     L.qpg_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, c_int]
     L.qpg_batch_create.argtypes = [C.c_void_p, c_int, c_int, c_int, c_int, c_int, C.POINTER(Settings), C.POINTER(C.c_void_p)]
     L.qpg_batch_set_problem.argtypes = [C.c_void_p, c_int, pi, pi, pf, pi, pi, pf, pf, c_float, pf, pf]
-    for f in ("qpg_batch_setup", "qpg_batch_solve", "qpg_batch_sync"):
+    for f in ("qpg_batch_setup", "qpg_batch_solve", "qpg_batch_sync", "qpg_batch_begin_solve"):
         getattr(L, f).argtypes = [C.c_void_p]
     L.qpg_batch_warm_start.argtypes = [C.c_void_p, pf, pf]
     L.qpg_batch_iterate.argtypes = [C.c_void_p, c_int]
@@ -90,6 +89,8 @@ def load(path=None):
     L.qpg_batch_update_q.argtypes = [C.c_void_p, pf]
     L.qpg_batch_get_info.argtypes = [C.c_void_p, c_int, C.POINTER(Info)]
     L.qpg_batch_get_stats.argtypes = [C.c_void_p, c_int, C.POINTER(Stats)]
+    L.qpg_batch_get_info_all.argtypes = [C.c_void_p, C.POINTER(Info)]
+    L.qpg_batch_get_stats_all.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.qpg_batch_get_solution.argtypes = [C.c_void_p, pf, pf]
     L.qpg_batch_get_vector.argtypes = [C.c_void_p, C.c_char_p, c_int, pf, c_int]
     L.qpg_batch_set_vector.argtypes = [C.c_void_p, C.c_char_p, c_int, pf, c_int]
@@ -110,6 +111,7 @@ def load(path=None):
     L.qpg_ldlchol_matrix.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf]
     L.qpg_sparse_matvec.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf, C.c_int, C.c_int, pf, pf]
     L.qpg_batch_ldlsolve_all.argtypes = [C.c_void_p, c_int, C.POINTER(C.c_float)]
+    L.qpg_ctx_hbm_copy_gbs.argtypes = [C.c_void_p, C.c_size_t, c_int, C.POINTER(C.c_float)]
     _LIBS[path] = L
     return L
 
@@ -126,6 +128,7 @@ SYMBOLS = [
     "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints", "qpg_ldldowndate_leaving_constraints",
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
     "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
+    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs",
 ]
 
 

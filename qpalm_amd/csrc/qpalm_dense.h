@@ -363,8 +363,8 @@ template <int RPT>
 #ifndef QP_NI_FACTOR
 #define QP_NI_FACTOR QPNI
 #endif
-QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *lds_, int64_t *tdbg_, int dbgf_ = 0) {
-  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), dbgf = QP_UNIFORM(dbgf_); /* wave-uniform arguments back to SGPRs */
+QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *lds_, int64_t *tdbg_) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_); /* wave-uniform arguments back to SGPRs */
   int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* the timers live in the kernel's static LDS */
   qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_;
   FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
@@ -393,10 +393,10 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *l
      * p(r,c2) <- fma(-l(r,c), p(c2,c), p(r,c2)) for c ascending, l(r,c) = p(r,c) / p(c,c). ---------- */
     for (int e = tid; e < NB * NB; e += QP_T) {
       const int c = e / NB, r = e % NB;
-      F.Ld[r][c] = (r >= c && r < jb && !(dbgf & 16)) ? L[(size_t)(J + c) * ld + (J + r)] : ((r == c) ? 1.0 : 0.0);
+      F.Ld[r][c] = (r >= c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (wid == 0 && !(dbgf & 8)) {
+    if (wid == 0) {
 #pragma unroll 1
       for (int c = 0; c < jb; c++) {
         const int ln = QP_FRESH_LANE(lane);
@@ -706,7 +706,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
     const int grank = r0 + lane;
     const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
     const int J0 = (jmin / NB) * NB;
-    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1; }
+    if (tid == 0) {
+      const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1;
+      tdbg[QPG_CNT_SWEEPS] += 1;
+      tdbg[QPG_CNT_SWEEP_ENTRIES] += (long long)(n - J0) * (n - J0 - 1) / 2 + (n - J0); /* strict lower part of columns J0.. + pivots */
+    }
     const int nblk = (n - J0 + NB - 1) / NB;
     qp_gdouble *dummy = Wst + (size_t)QPG_KMAX * n;
     /* prologue: rows of block 0 to the hand-over buffer, diagonal block 0 to LDS */

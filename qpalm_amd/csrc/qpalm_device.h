@@ -82,7 +82,9 @@ static __device__ __forceinline__ char *qp_dyn_lds_opaque_() {
 #define QP_CLOCK() ((long long)wall_clock64())
 #define QP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x) /* value is wave-uniform: keep it in an SGPR */
 /* stops LICM/CSE from keeping ~100 per-array addresses live across the whole iteration loop */
-#define QP_OPAQUE(x) asm volatile("" : "+s"(x))
+/* (readfirstlane first: after a branch the compiler could not prove uniform the value may sit in a VGPR phi, and a
+ * plain "+s" constraint is then an illegal VGPR-to-SGPR copy; on an SGPR value the readfirstlane folds away) */
+#define QP_OPAQUE(x) do { (x) = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); } while (0)
 #define QP_OPAQUE_V(x) asm volatile("" : "+v"(x)) /* same for a value that lives in a VGPR (function arguments) */
 /* the lane id recomputed on the spot (2 VALU ops): inside latency-critical loops this keeps lane-derived
  * LDS addresses and lane masks out of long-lived (= spilled, under the 128-VGPR cap) registers */

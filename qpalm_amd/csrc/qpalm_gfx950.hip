@@ -10,9 +10,11 @@
 #include "qpalm_kernels.h"
 
 static std::string g_rt_err;
+static int g_rt_sticky = 0; /* a failed copy/memset is remembered until the API call returns (api_ok() in qpalm_capi.inc) */
 static int rt_check(hipError_t e, const char *what) {
   if (e == hipSuccess) return 0;
   g_rt_err = std::string(what) + ": " + hipGetErrorString(e);
+  g_rt_sticky = 1;
   return 1;
 }
 static int rt_sync() {
@@ -38,10 +40,12 @@ template <class K> static void rt_allow_lds(K kernel, size_t shmem) {
 #define RT_DEVICE_INIT(device, why) rt_device_init((device), (why))
 #define RT_MALLOC(pp, bytes) rt_check(hipMalloc((void **)(pp), (bytes)), "hipMalloc")
 #define RT_FREE(p) (void)hipFree(p)
-#define RT_MEMCPY_H2D(dst, src, bytes) (void)rt_check(hipMemcpy((void *)(dst), (const void *)(src), (bytes), hipMemcpyHostToDevice), "hipMemcpy H2D")
-#define RT_MEMCPY_D2H(dst, src, bytes) (void)rt_check(hipMemcpy((void *)(dst), (const void *)(src), (bytes), hipMemcpyDeviceToHost), "hipMemcpy D2H")
-#define RT_MEMSET(dst, val, bytes) (void)rt_check(hipMemset((void *)(dst), (val), (bytes)), "hipMemset")
+#define RT_MEMCPY_H2D(dst, src, bytes) rt_check(hipMemcpy((void *)(dst), (const void *)(src), (bytes), hipMemcpyHostToDevice), "hipMemcpy H2D")
+#define RT_MEMCPY_D2H(dst, src, bytes) rt_check(hipMemcpy((void *)(dst), (const void *)(src), (bytes), hipMemcpyDeviceToHost), "hipMemcpy D2H")
+#define RT_MEMSET(dst, val, bytes) rt_check(hipMemset((void *)(dst), (val), (bytes)), "hipMemset")
 #define RT_SYNC() rt_sync()
+#define RT_STICKY() (g_rt_sticky)
+#define RT_STICKY_CLEAR() (g_rt_sticky = 0)
 #define RT_LAST_ERROR() (g_rt_err.c_str())
 #define RT_LAUNCH(kernel, grid, block, shmem, ...)                                         \
   do {                                                                                      \

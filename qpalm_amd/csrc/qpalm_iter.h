@@ -239,7 +239,7 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
  * factorisation plumbing
  * =========================================================================================== */
 template <int RPT>
-QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds, tdbg, V.dbg_flags); }
+QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds, tdbg); }
 template <int RPT>
 QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *up, int n_up,
                     const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
@@ -250,6 +250,27 @@ QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst
 /* =============================================================================================
  * update_sigma (iteration.c:86-145) + ldlupdate_sigma_changed (solver_interface.c:443-503)
  * =========================================================================================== */
+/* First half of ldlupdate_sigma_changed (solver_interface.c:455-460,492): the changed rows (listed in a.enter()) get
+ * At_scale <- sqrt(1 - 1/At_scale^2), then every column of At_sqrt_sigma is scaled by At_scale (1.0 = untouched).
+ * One copy, used by the iteration loop and by the boundary operation qpg_ldlupdate_sigma_changed. */
+QPN void dev_ldlupdate_sigma_scale(const QpArrays &a, int nchg) {
+  const int m = a.m, tid = threadIdx.x;
+  __syncthreads();
+  for (int k = tid; k < nchg; k += QP_T) {
+    const int row = a.enter()[k];
+    double s = a.At_scale()[row];
+    s = s * s;
+    s = QP_SQRT(1 - 1 / s);
+    a.At_scale()[row] = s;
+  }
+  __syncthreads();
+  for (int k = tid; k < m; k += QP_T) {
+    const double s = a.At_scale()[k];
+    if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s;
+  }
+  __syncthreads();
+}
+
 /* Part 1: new sigma, rescaled At_sqrt_sigma, list of changed rows (in a.enter()).  Returns the number
  * of rank-1 updates ldlupdate_sigma_changed has to apply (0: nothing to do or a refactorisation was
  * requested); the update itself runs at dev_solve's single linear-algebra site, then part 2. */
@@ -296,15 +317,7 @@ QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
     if (tid == 0) I.s.reset_newton = 1;
   } else if (nchg == 0) {
   } else {
-    /* ldlupdate_sigma_changed */
-    for (int k = tid; k < nchg; k += QP_T) {
-      const int row = a.enter()[k];
-      double s = a.At_scale()[row];
-      s = s * s;
-      s = QP_SQRT(1 - 1 / s);
-      a.At_scale()[row] = s;
-      for (int e = a.Atp()[row]; e < a.Atp()[row + 1]; e++) a.Atss()[e] *= s;
-    }
+    dev_ldlupdate_sigma_scale(a, nchg);
     nupd = nchg;
   }
   __syncthreads();
@@ -526,6 +539,28 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   return tau;
 }
 
+/* compute_dual_objective (iteration.c:272-299): rhs = Aty + q, solve with the resident factor of Q (LD_Q),
+ * dual = -1/2 rhs' Q^{-1} rhs - sum_i (y_i > 0 ? y_i bmax_i : y_i bmin_i), unscaled by 1/c, plus the constant.
+ * The two sums use the workgroup's fixed reduction tree (the CPU sums sequentially / in groups of four). */
+QPN double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const double *LQ, const double *DgQ, IterShared &I, char *lds) {
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  double *rhs = V.dual_rhs + (size_t)b * n, *sol = a.temp_n();
+  __syncthreads();
+  for (int j = tid; j < n; j += QP_T) { const double r = a.Aty()[j] + 1.0 * a.q()[j]; rhs[j] = r; sol[j] = r; }
+  __syncthreads();
+  dense_solve(LQ, DgQ, n, V.ld, sol, lds, V.lds_bytes);
+  double vm[1] = {0.0}, vs[2] = {0.0, 0.0};
+  for (int j = tid; j < n; j += QP_T) vs[0] += rhs[j] * sol[j];
+  for (int i = tid; i < m; i += QP_T) { const double yv = a.y()[i]; vs[1] += yv > 0 ? yv * a.bmax()[i] : yv * a.bmin()[i]; }
+  block_reduce<0, 2>(I.S, vm, vs);
+  double dobj = 0;
+  dobj -= 0.5 * vs[0];
+  dobj -= vs[1];
+  if (I.s.has_scaling) dobj *= I.s.sc_cinv;
+  dobj += V.c0[b];
+  return dobj;
+}
+
 /* =============================================================================================
  * the loop body of qpalm_solve (src/qpalm.c:484-711) for one QP; runs at most `budget` iterations
  * =========================================================================================== */
@@ -535,6 +570,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
   QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x;
   double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * V.wst_stride;
+  double *LQ = V.LQ ? V.LQ + (size_t)slot * V.ld * n : nullptr, *DgQ = V.DgQ ? V.DgQ + (size_t)slot * n : nullptr;
   __syncthreads();
   if (tid == 0) I.s = V.sc[b];
   __syncthreads();
@@ -549,20 +585,33 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     __syncthreads();
     if (!I.s.initialized) dev_warm_start(V, a, b, 0, 0, I);
     if (tid == 0) {
-      I.s.dual_objective = 0;
+      I.s.dual_objective = 0; /* QPALM_NULL (B8) unless dual termination is enabled */
+      I.s.dual_pending = st.enable_dual_termination ? 1 : 0;
       I.s.iter = 0; I.s.iter_out = 0; I.s.prev_iter = 0; I.s.no_change = 0;
       I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
       I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot;
       I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
       I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
-      for (int k = 0; k < 16; k++) I.s.ticks_dbg[k] = 0;
+      for (int k = 0; k < QPG_NDBG; k++) I.s.ticks_dbg[k] = 0;
     }
     __syncthreads();
   }
   const int scal = I.s.has_scaling, prox = (int)st.proximal;
   int executed = 0;
   while (true) {
+    /* At most ONE linear-algebra operation per pass, so form_schur / factor / update each have a
+     * single call site (one copy of those loop nests in the kernel):
+     *   1 refactor Q + A' Sigma_act A   2 update entering / downdate leaving   3 factor Q (+ I/gamma)
+     *   4 update for changed sigma       5 Gershgorin bound for boost_gamma      6 boost_gamma without bound
+     *   7 factor of Q alone into the second slot (LD_Q of qpalm.c:466-467, dual termination) */
+    int la = 0, n_sig = 0, action = 0, nchange = 0, kind = QP_KIND_NEWTON;
+    double gam = I.s.gamma;
+    long long tr0 = 0;
+    __syncthreads();
+    const bool dual_init = (QP_UNIFORM(I.s.dual_pending) != 0); /* workgroup-uniform: keep the branch scalar */
+    if (dual_init) la = 7;
+    else {
     if (I.s.iter >= st.max_iter) { /* qpalm.c:712-735 */
       dev_store_solution(V, a, b, I);
       if (tid == 0) { I.s.status = QPG_MAX_ITER_REACHED; I.s.done = 1; I.s.initialized = 0; I.s.in_solve = 0; }
@@ -571,7 +620,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     if (executed >= budget) break;
     executed++;
     QP_OPAQUE(a.b);
-    const long long tr0 = QP_CLOCK();
+    tr0 = QP_CLOCK();
     /* ---- dx-dependent quantities of is_dual_infeasible (termination.c:190-203) -------------- */
     double vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
     for (int j = tid; j < n; j += QP_T) {
@@ -624,7 +673,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), a.yh(), [&](int r, double s) { a.Atyh()[r] = s; });
     __syncthreads();
     /* ---- df, dphi (iteration.c:37-47) + dual residual norms (termination.c:61-129) ---------- */
-    const double gam = I.s.gamma;
+    gam = I.s.gamma;
     const double mginv = -1 / gam, tg = -I.s.tau / gam;
     for (int j = tid; j < n; j += QP_T) {
       const double atyh = a.Atyh()[j];
@@ -664,7 +713,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       if (scal) mx *= s.sc_cinv;
       s.eps_dua = st.eps_abs + st.eps_rel * mx;
       s.eps_dua_in = s.eps_abs_in + s.eps_rel_in * mx;
-      int kind;
+      int kind = QP_KIND_NEWTON;
       const double eps_pinf = st.eps_prim_inf * vm[2];
       int prim_inf = 0, dual_inf = 0;
       if (eps_pinf != 0) prim_inf = (vm[7] <= eps_pinf) && (vs[0] <= -eps_pinf);
@@ -683,7 +732,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     }
     __syncthreads();
     QP_OPAQUE(a.b);
-    const int kind = I.kind;
+    kind = I.kind;
     if (kind == QP_KIND_TERMINATED) {
       const int status = I.s.status;
       if (status == QPG_SOLVED) dev_store_solution(V, a, b, I);
@@ -696,11 +745,6 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       if (tid == 0) { I.s.done = 1; I.s.initialized = 0; I.s.in_solve = 0; I.s.last_kind = QP_KIND_TERMINATED; }
       break;
     }
-    /* At most ONE linear-algebra operation per iteration, so form_schur / factor / update each have a
-     * single call site (one copy of those loop nests in the kernel):
-     *   1 refactor Q + A' Sigma_act A   2 update entering / downdate leaving   3 factor Q (+ I/gamma)
-     *   4 update for changed sigma       5 Gershgorin bound for boost_gamma      6 boost_gamma without bound */
-    int la = 0, n_sig = 0, action = 0, nchange = 0;
     if (kind == QP_KIND_OUTER || kind == QP_KIND_FORCED) { /* qpalm.c:585-660 */
       if (tid == 0) I.s.no_change = 0;
       __syncthreads();
@@ -709,6 +753,16 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
         for (int i = tid; i < m; i += QP_T) a.y()[i] = a.yh()[i];
         for (int j = tid; j < n; j += QP_T) a.Aty()[j] = a.Atyh()[j];
         __syncthreads();
+        if (st.enable_dual_termination) { /* qpalm.c:543-583 */
+          const double dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
+          if (tid == 0) I.s.dual_objective = dobj;
+          __syncthreads();
+          if (QP_UNIFORM((int)(dobj > st.dual_objective_limit))) { /* same value in every lane: scalar branch */
+            dev_store_solution(V, a, b, I);
+            if (tid == 0) { I.s.status = QPG_DUAL_TERMINATED; I.s.done = 1; I.s.initialized = 0; I.s.in_solve = 0; I.s.last_kind = QP_KIND_TERMINATED; }
+            break;
+          }
+        }
         if (tid == 0) {
           I.s.eps_abs_in = qmax(st.eps_abs, st.rho * I.s.eps_abs_in);
           I.s.eps_rel_in = qmax(st.eps_rel, st.rho * I.s.eps_rel_in);
@@ -747,13 +801,21 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       else action = 3;
       la = action;
     }
+    } /* !dual_init */
     QP_OPAQUE(a.b);
     const long long t0 = QP_CLOCK();
     double gersh_ub = 0.0;
-    if (la == 1 || la == 3 || la == 5) {
-      gersh_ub = form_schur(V, b, L, la == 5, la != 3, (la != 5) && (prox != 0), gam, I.S, lds);
+    if (la == 1 || la == 3 || la == 5 || la == 7) {
+      double *Lt = (la == 7) ? LQ : L, *Dt = (la == 7) ? DgQ : Dg;
+      gersh_ub = form_schur(V, b, Lt, la == 5, la == 1 || la == 5, (la == 1 || la == 3) && (prox != 0), gam, I.S, lds);
       if (tid == 0) I.s.ticks_dbg[3] += QP_CLOCK() - t0;
-      if (la != 5) dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
+      if (la != 5) dev_factor<RPT>(V, Lt, Dt, lds, I.s.ticks_dbg);
+      if (dual_init) { /* qpalm.c:459-468: LD_Q is ready, the dual objective of the starting point (scalar branch) */
+        const double dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
+        if (tid == 0) { I.s.dual_objective = dobj; I.s.dual_pending = 0; }
+        __syncthreads();
+        continue;
+      }
     } else if (la == 2 || la == 4) {
       const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
       dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg);
@@ -762,7 +824,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     QP_OPAQUE(a.b);
     if (la == 4) {
       dev_update_sigma_post(a, I, n_sig);
-      if (tid == 0) { I.s.n_sweeps += (n_sig + 15) / 16; I.s.ticks_update += t1 - t0; }
+      if (tid == 0) { I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
     } else if (la >= 5) dev_boost_gamma_apply(V, a, I, gersh_ub);
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
@@ -775,7 +837,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
         I.s.reset_newton = 0;
         if (action == 1) { I.s.n_refactor++; I.s.ticks_factor += t1 - t0; }
         if (action == 3) { I.s.n_factor_Q++; I.s.ticks_factor += t1 - t0; }
-        if (action == 2) { I.s.n_rank1 += nchange; I.s.n_sweeps += (nchange + 15) / 16; I.s.ticks_update += t1 - t0; }
+        if (action == 2) { I.s.n_rank1 += nchange; I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
         I.s.n_solve++; I.s.ticks_solve += t2 - t1;
         I.s.last_fact = action;
       }

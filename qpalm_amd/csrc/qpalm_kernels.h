@@ -217,23 +217,11 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
       break;
     case QP_OP_UPDATE_ENTER: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), 0, I.S, lds, I.s.ticks_dbg); break;
     case QP_OP_DOWNDATE_LEAVE: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), 0, a.leave(), I.s.nb_leave, I.S, lds, I.s.ticks_dbg); break;
-    case QP_OP_UPDATE_SIGMA: { /* solver_interface.c:443-503; At_scale and the changed list (enter) are set */
+    case QP_OP_UPDATE_SIGMA: { /* solver_interface.c:443-503; At_scale and the changed list (enter) were set by the caller */
       const int nchg = I.s.nb_sigma_changed;
-      for (int k = tid; k < nchg; k += QP_T) {
-        const int row = a.enter()[k];
-        double s = a.At_scale()[row];
-        s = s * s; s = QP_SQRT(1 - 1 / s);
-        a.At_scale()[row] = s;
-      }
-      __syncthreads();
-      for (int k = tid; k < m; k += QP_T) { const double s = a.At_scale()[k]; if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s; }
-      __syncthreads();
+      dev_ldlupdate_sigma_scale(a, nchg);
       dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds, I.s.ticks_dbg);
-      for (int k = tid; k < m; k += QP_T) {
-        const double s = 1.0 / a.At_scale()[k];
-        a.At_scale()[k] = s;
-        if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s;
-      }
+      dev_update_sigma_post(a, I, nchg);
       break;
     }
     case QP_OP_SOLVE:
@@ -270,6 +258,20 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_ldlsolve_all(qpg_view V, 
       dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes);
     }
   }
+}
+
+/* Plain HBM copy (16 bytes per lane and step, grid-stride): the attainable-bandwidth yardstick that bench.py quotes
+ * next to the 8 TB/s spec figure ("measure the attainable ceiling on the box"). */
+__global__ __launch_bounds__(256) void k_hbm_copy(const double *__restrict__ src, double *__restrict__ dst, size_t npairs) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+#ifdef QPALM_EMU
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) { dst[2 * i] = src[2 * i]; dst[2 * i + 1] = src[2 * i + 1]; }
+#else
+  typedef double copy_d2 __attribute__((ext_vector_type(2)));
+  const copy_d2 *s2 = (const copy_d2 *)src;
+  copy_d2 *d2 = (copy_d2 *)dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) d2[i] = s2[i];
+#endif
 }
 
 #endif

@@ -35,6 +35,12 @@ typedef struct {
   double max_rank_update_fraction;
 } qpg_settings;
 
+#define QPG_NDBG 20
+#define QPG_CNT_SWEEP_ENTRIES 16 /* entries of L (doubles) the rank-update sweeps read AND wrote: sum of nnz(L[:, J0:]) */
+#define QPG_CNT_SWEEPS 17        /* sweeps over the panel (<= K ranks each, K = 16 or 8 by instantiation) */
+#define QPG_CNT_FACTOR_REREAD 18 /* entries of L re-read by the left-looking panel updates of the factorisation */
+#define QPG_CNT_SPARE 19
+
 /* per-QP scalar state: everything qpalm_solve keeps in locals or in QPALMWorkspace scalars
  * (src/qpalm.c:401-482, include/types.h:197-314), so that a solve can be suspended after any
  * iteration and resumed by a later launch. */
@@ -48,15 +54,17 @@ typedef struct {
   int32_t status, done, initialized, gamma_maxed, reset_newton, in_solve;
   int32_t nb_active, nb_enter, nb_leave, nb_sigma_changed;
   int32_t last_kind, last_fact, slot, has_scaling;
+  int32_t dual_pending, pad_i0; /* dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
   /* work counters (device side statistics for the roofline accounting in bench.py) */
   int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_spmv;
   int64_t ticks_total, ticks_factor, ticks_update, ticks_solve, ticks_linesearch, ticks_resid;
-  int64_t ticks_dbg[16]; /* fine-grained phase timers (100 MHz ticks), see QPGStats.ms_dbg */
+  int64_t ticks_dbg[QPG_NDBG]; /* [0..15] fine-grained phase timers (100 MHz ticks), see QPGStats.ms_dbg;
+                                  [16..] work counters written by the linear-algebra functions themselves (QPG_CNT_*) */
 } qpg_scalars;
 
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
-  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, dbg_flags, pad2;
+  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, pad1, pad2;
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.
    * Q: lower CSC.  Qf: both triangles (row == column compressed), with permutation into Q. */
   int32_t *Ap, *Ai, *Atp, *Ati, *Atperm, *Ainv, *Qp, *Qi, *Qfp, *Qfi, *Qfperm; /* Ainv: position in A' of every entry of A */
@@ -76,6 +84,10 @@ typedef struct {
   /* factor slots */
   double *L;   /* [nslots][ld*n] column-major, unit lower, strict lower part used */
   double *Dg;  /* [nslots][n] */
+  double *LQ;  /* [nslots][ld*n] second resident factor: LD_Q = LDL' of Q for compute_dual_objective (qpalm.c:466-467);
+                  allocated only when enable_dual_termination is set, else NULL */
+  double *DgQ; /* [nslots][n] */
+  double *dual_rhs; /* [B][n] Aty + q (the reference uses neg_dphi for it, iteration.c:276) */
   double *Wst; /* [nslots][wst_stride]: QPG_KMAX*n staging for rank-update vectors + a dummy row area */
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
   qpg_scalars *sc; /* [B] */

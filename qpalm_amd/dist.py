@@ -7,7 +7,9 @@ solution.y and the info records to rank 0.  A single QP is never split across GP
 """
 import numpy as np
 
-INFO_FIELDS = ("iter", "iter_out", "status_val", "pri_res_norm", "dua_res_norm", "dua2_res_norm", "objective")
+# QPALMInfo (include/types.h:76-95) as one fp64 row per QP; the status string is derived from status_val on arrival
+INFO_FIELDS = ("iter", "iter_out", "status_val", "pri_res_norm", "dua_res_norm", "dua2_res_norm", "objective", "dual_objective",
+               "setup_time", "solve_time", "run_time")
 
 
 class _DeviceArray:
@@ -33,12 +35,15 @@ def shard_indices(nqp, world, rank):
     return np.arange(rank, nqp, world)
 
 
-def pack_info(batch):
+def info_matrix(batch):
+    """[B][len(INFO_FIELDS)] fp64: the QPALMInfo records of the batch (one device-to-host copy), ready for the gather"""
     out = np.zeros((batch.B, len(INFO_FIELDS)))
-    for b in range(batch.B):
-        info = batch.info(b)
+    for b, info in enumerate(batch.infos()):
         out[b] = [float(getattr(info, k)) for k in INFO_FIELDS]
     return out
+
+
+pack_info = info_matrix
 
 
 def solve_sharded(problems, make_batch, dist=None, device=None):

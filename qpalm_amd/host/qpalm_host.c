@@ -210,6 +210,7 @@ void qpalm_solve(QPALMWorkspace *work) { /* qpalm.c:401-736 */
     /* host-driven, one iteration per launch, so that progress can be printed (util.c:107-206) */
     print_header();
     qpg_int left = 1;
+    qpg_batch_begin_solve(BT(work)); /* a finished workspace starts a new solve (qpalm.c:409-424) */
     qpg_batch_iterate(BT(work), 1);
     while (qpg_batch_num_unfinished(BT(work), &left) == QPG_OK && left > 0) {
       QPGInfo gi; QPGStats st;
@@ -285,7 +286,13 @@ void qpalm_cleanup(QPALMWorkspace *work) { /* qpalm.c:874-1096 */
 }
 
 /* ---- solver_interface.h ------------------------------------------------------------------------ */
-static QPALMWorkspace *g_last_work; /* mat_vec has no workspace argument: the context of the last setup is used */
+/* mat_vec / mat_tpose_vec return void in the reference (solver_interface.h:33,47): a backend failure is made loud by
+ * filling the result with NaN, a message on stderr and qpalm_backend_error() */
+static void matvec_failed(solver_dense *y, size_t len) {
+  snprintf(g_host_err, sizeof g_host_err, "mat_vec: %s", qpg_last_error());
+  fprintf(stderr, "qpalm (gfx950 backend): %s\n", g_host_err);
+  for (size_t k = 0; k < len; k++) ((c_float *)y->x)[k] = NAN;
+}
 
 static qpg_ctx *any_ctx(void) {
   static qpg_ctx *c = NULL;
@@ -294,18 +301,18 @@ static qpg_ctx *any_ctx(void) {
 }
 
 void mat_vec(solver_sparse *A, solver_dense *x, solver_dense *y, solver_common *c) { /* solver_interface.c:252-262 */
-  (void)c; (void)g_last_work;
+  (void)c;
   qpg_ctx *ctx = any_ctx();
-  if (!ctx) return;
-  qpg_sparse_matvec(ctx, (qpg_int)A->nrow, (qpg_int)A->ncol, (const qpg_int *)A->p, (const qpg_int *)A->i, (const qpg_float *)A->x,
-                    A->stype, 0, (const qpg_float *)x->x, (qpg_float *)y->x);
+  if (!ctx || qpg_sparse_matvec(ctx, (qpg_int)A->nrow, (qpg_int)A->ncol, (const qpg_int *)A->p, (const qpg_int *)A->i, (const qpg_float *)A->x,
+                                A->stype, 0, (const qpg_float *)x->x, (qpg_float *)y->x) != QPG_OK)
+    matvec_failed(y, A->stype ? A->ncol : A->nrow);
 }
 void mat_tpose_vec(solver_sparse *A, solver_dense *x, solver_dense *y, solver_common *c) { /* solver_interface.c:264-274 */
   (void)c;
   qpg_ctx *ctx = any_ctx();
-  if (!ctx) return;
-  qpg_sparse_matvec(ctx, (qpg_int)A->nrow, (qpg_int)A->ncol, (const qpg_int *)A->p, (const qpg_int *)A->i, (const qpg_float *)A->x,
-                    A->stype, 1, (const qpg_float *)x->x, (qpg_float *)y->x);
+  if (!ctx || qpg_sparse_matvec(ctx, (qpg_int)A->nrow, (qpg_int)A->ncol, (const qpg_int *)A->p, (const qpg_int *)A->i, (const qpg_float *)A->x,
+                                A->stype, 1, (const qpg_float *)x->x, (qpg_float *)y->x) != QPG_OK)
+    matvec_failed(y, A->ncol);
 }
 void mat_inf_norm_cols(solver_sparse *M, c_float *E) { /* solver_interface.c:276-292: host loop over the user's matrix */
   const c_int *Mp = (const c_int *)M->p; const c_float *Mx = (const c_float *)M->x;

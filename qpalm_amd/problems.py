@@ -106,6 +106,22 @@ def random_mpc_qp(T=10, nx=10, nu=5, seed=0, x_init_scale=1.0, x_init=None):
     return QP(n, A.shape[0], Qp, Qi, Qx, Ap, Ai, Ax, q, bmin, bmax)
 
 
+def replicated_qp(base, copies, seed=0, pert=0.05):
+    """Block-diagonal QP made of `copies` randomly perturbed copies of `base` (a small fixture QP): a larger instance
+    that keeps the base problem's behaviour (e.g. the reference's basic_qp reaches boost_gamma, iteration.c:158-211)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Q, A = base.Q_full(), base.A_mat()
+    Qs, As, qs = [], [], []
+    for _ in range(copies):
+        Qs.append(Q * (1 + pert * rng.standard_normal()))
+        As.append(sp.csc_matrix(A.multiply(1 + pert * rng.standard_normal(A.shape))))
+        qs.append(base.q * (1 + pert * rng.standard_normal(base.n)))
+    Qf, Af = sp.block_diag(Qs, format="csc"), sp.block_diag(As, format="csc")
+    Qp, Qi, Qx = _csc(sp.tril(Qf))
+    Ap, Ai, Ax = _csc(Af)
+    return QP(Qf.shape[0], Af.shape[0], Qp, Qi, Qx, Ap, Ai, Ax, np.concatenate(qs), np.tile(base.bmin, copies), np.tile(base.bmax, copies))
+
+
 def fixture_qp(p):
     """QP from a tests/golden/reference_tests.json problem dict."""
     return QP(p["n"], p["m"], np.array(p["Qp"], np.int64), np.array(p["Qi"], np.int64), np.array(p["Qx"], float),

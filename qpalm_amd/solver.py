@@ -45,6 +45,14 @@ class Context:
             setattr(s, k, v)
         return s
 
+    def hbm_copy_gbs(self, nbytes=1 << 30, reps=5):
+        """measured copy bandwidth of the device (GB/s, read + write): the attainable-HBM yardstick of bench.py"""
+        g = C.c_float(0.0)
+        rc = self.L.qpg_ctx_hbm_copy_gbs(self.h, int(nbytes), int(reps), C.byref(g))
+        if rc != 0:
+            raise QpgError(rc, self.L.qpg_last_error().decode())
+        return float(g.value)
+
     def close(self):
         if self.h:
             self.L.qpg_ctx_destroy(self.h)
@@ -132,8 +140,22 @@ class QpalmBatch:
         self._check(self.L.qpg_batch_get_solution(self.h, fptr(x), fptr(y)))
         return x, y
 
+    def infos(self):
+        """QPALMInfo of every QP (one device-to-host copy)."""
+        out = (Info * self.B)()
+        self._check(self.L.qpg_batch_get_info_all(self.h, out))
+        return out
+
+    def stats_all(self):
+        out = (Stats * self.B)()
+        self._check(self.L.qpg_batch_get_stats_all(self.h, out))
+        return out
+
+    def begin_solve(self):
+        self._check(self.L.qpg_batch_begin_solve(self.h))
+
     def statuses(self):
-        return np.array([int(self.info(b).status_val) for b in range(self.B)])
+        return np.array([int(i.status_val) for i in self.infos()])
 
     _LEN_N = {"x", "Qx", "Aty", "x_prev", "x0", "Atyh", "df", "dphi", "dphi_prev", "d", "Qd", "delta_x", "temp_n", "D", "Dinv",
               "solution_x", "q"}
@@ -147,6 +169,12 @@ class QpalmBatch:
 
     def vec(self, name, b=0):
         out = np.zeros(self._veclen(name))
+        self._check(self.L.qpg_batch_get_vector(self.h, name.encode(), int(b), fptr(out), len(out)))
+        return out
+
+    def named_vec(self, name, length, b=0):
+        """first `length` entries of a per-QP fp64 device array by its arena name (e.g. "At_sqrt_sigma")"""
+        out = np.zeros(int(length))
         self._check(self.L.qpg_batch_get_vector(self.h, name.encode(), int(b), fptr(out), len(out)))
         return out
 

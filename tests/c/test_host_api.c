@@ -14,6 +14,7 @@
 #include "golden_data.h"
 
 static int g_fail = 0, g_checks = 0;
+static int g_verbose = 0; /* the reference's suites keep the default verbose = TRUE: every suite runs with both settings */
 #define CHECK(cond) do { g_checks++; if (!(cond)) { g_fail++; printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); } } while (0)
 #define CHECK_NEAR(a, b, tol) do { g_checks++; if (!(fabs((a) - (b)) <= (tol))) { g_fail++; printf("FAIL %s:%d: %s=%.15g vs %.15g (tol %g)\n", __FILE__, __LINE__, #a, (double)(a), (double)(b), (double)(tol)); } } while (0)
 
@@ -34,7 +35,7 @@ static void free_data(QPALMData *d) { qpalm_sparse_free(&d->A); qpalm_sparse_fre
 /* suite_basic_qp (tests/src/test_basic_qp.c:90-427) */
 static void basic_defaults(QPALMSettings *s) {
   qpalm_set_default_settings(s);
-  s->max_rank_update_fraction = 1.0; s->verbose = 0;
+  s->max_rank_update_fraction = 1.0; s->verbose = g_verbose;
   s->eps_abs = 1e-6; s->eps_rel = 1e-6; s->gamma_init = 1e1;
 }
 static void check_basic_solution(QPALMWorkspace *work) {
@@ -73,13 +74,20 @@ static void suite_basic_qp(void) {
   work = qpalm_setup(data, &s); qpalm_solve(work); CHECK(work->info->status_val == QPALM_MAX_ITER_REACHED); qpalm_cleanup(work);
   basic_defaults(&s); s.sigma_max = 1e3; work = qpalm_setup(data, &s); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
   basic_defaults(&s); s.time_limit = 0.01 * 1e-3; work = qpalm_setup(data, &s); qpalm_solve(work); CHECK(work->info->status_val == QPALM_TIME_LIMIT_REACHED); qpalm_cleanup(work);
+  /* test_basic_qp_dual_objective (test_basic_qp.c:334-349) */
+  basic_defaults(&s); s.enable_dual_termination = TRUE; work = qpalm_setup(data, &s); CHECK(work != QPALM_NULL); qpalm_solve(work);
+  check_basic_solution(work); CHECK_NEAR(work->info->objective, work->info->dual_objective, 1e-5); qpalm_cleanup(work);
+  /* test_basic_qp_dual_early_termination (test_basic_qp.c:351-362) */
+  basic_defaults(&s); s.enable_dual_termination = TRUE; s.dual_objective_limit = -1000000000.0;
+  work = qpalm_setup(data, &s); qpalm_solve(work);
+  CHECK(work->info->status_val == QPALM_DUAL_TERMINATED); CHECK(work->info->iter_out == 0); qpalm_cleanup(work);
   free_data(data);
 }
 
 /* suite_degen_hess (tests/src/test_degen_hess.c:95-105) */
 static void suite_degen_hess(void) {
   QPALMData *data = make_data(&golden_degen_hess);
-  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.max_rank_update_fraction = 1.0; s.verbose = 0;
+  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.max_rank_update_fraction = 1.0; s.verbose = g_verbose;
   QPALMWorkspace *work = qpalm_setup(data, &s);
   qpalm_solve(work);
   CHECK(work->info->status_val == QPALM_SOLVED);
@@ -93,7 +101,7 @@ static void suite_infeasible(void) {
     QPALMData *data = make_data(which ? &golden_dua_inf_qp : &golden_prim_inf_qp);
     const int prox[4] = {1, 1, 0, 0}, scal[4] = {2, 0, 2, 0};
     for (int k = 0; k < 4; k++) {
-      QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.max_rank_update_fraction = 1.0; s.verbose = 0;
+      QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.max_rank_update_fraction = 1.0; s.verbose = g_verbose;
       s.proximal = prox[k]; s.scaling = scal[k];
       QPALMWorkspace *work = qpalm_setup(data, &s); qpalm_solve(work);
       CHECK(work->info->status_val == (which ? QPALM_DUAL_INFEASIBLE : QPALM_PRIMAL_INFEASIBLE));
@@ -106,7 +114,7 @@ static void suite_infeasible(void) {
 /* suite_update (tests/src/test_update.c:91-148): three tests on one workspace */
 static void suite_update(void) {
   QPALMData *data = make_data(&golden_update);
-  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.scaling = 2; s.proximal = TRUE; s.verbose = 0;
+  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.scaling = 2; s.proximal = TRUE; s.verbose = g_verbose;
   QPALMWorkspace *work = qpalm_setup(data, &s);
   qpalm_solve(work);
   CHECK(work->info->status_val == QPALM_SOLVED); CHECK_NEAR(work->solution->x[0], -0.1, 1e-5); CHECK_NEAR(work->solution->x[1], 0.3, 1e-5);
@@ -160,10 +168,12 @@ static void suite_solver(void) {
 
 int main(void) {
   suite_solver();
-  suite_basic_qp();
-  suite_degen_hess();
-  suite_infeasible();
-  suite_update();
+  for (g_verbose = 0; g_verbose < 2; g_verbose++) { /* 1 = the host-driven one-iteration-per-launch path with printing */
+    suite_basic_qp();
+    suite_degen_hess();
+    suite_infeasible();
+    suite_update();
+  }
   printf("%d checks, %d failures\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
 }

@@ -22,6 +22,8 @@ static int rt_malloc(void **pp, size_t bytes) { *pp = calloc(bytes ? bytes : 1, 
 #define RT_MEMCPY_D2H(dst, src, bytes) memcpy((void *)(dst), (const void *)(src), (bytes))
 #define RT_MEMSET(dst, val, bytes) memset((void *)(dst), (val), (bytes))
 #define RT_SYNC() 0
+#define RT_STICKY() 0
+#define RT_STICKY_CLEAR() do { } while (0)
 #define RT_LAST_ERROR() (g_rt_err.c_str())
 #define RT_LAUNCH(kernel, grid, block, shmem, ...) emu::launch(kernel, emu_dim3(grid), emu_dim3(block), (shmem), __VA_ARGS__)
 #define RT_TIMED_LAUNCH(ms, kernel, grid, block, shmem, ...)                                   \

@@ -43,15 +43,25 @@ def dense(p):
     return Q, A
 
 
-@pytest.mark.parametrize("n,m,nb", [(1000, 2000, 3), (1100, 2200, 2)])
+@pytest.mark.parametrize("n,m,nb", [(1000, 2000, 32), (1100, 2200, 8)])
 def test_full_size_matches_oracle(hip, n, m, nb):
+    """32 QPs of the benchmark batch (k_solve<2>, 16 ranks per sweep) and 8 at n = 1100 (k_solve<4>, 8 ranks per sweep)
+    against the oracle; the oracle solves run on a thread pool (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     probs = [bench_qp(n, m, 1000 + k) for k in range(nb)]
     bt = QpalmBatch(hip, probs, hip.default_settings(**ST))
     bt.solve()
     xs, ys = bt.solution()
-    for k, p in enumerate(probs):
+
+    def run_oracle(p):
         o = ob.OracleQP(*p.args(), c=p.c, settings=ob.default_settings(**ST))
         o.solve()
+        return o
+
+    with ThreadPoolExecutor(8) as ex:
+        oracles = list(ex.map(run_oracle, probs))
+    K = 16 if n <= 1024 else 8
+    for k, (p, o) in enumerate(zip(probs, oracles)):
         info, s = bt.info(k), bt.stats(k)
         assert int(info.status_val) == o.status_val == 1
         assert int(info.iter) == int(o.info.iter) and int(info.iter_out) == int(o.info.iter_out)
@@ -59,6 +69,9 @@ def test_full_size_matches_oracle(hip, n, m, nb):
         assert rel(xs[k], o.x) <= RTOL and rel(ys[k], o.y) <= RTOL
         assert abs(info.pri_res_norm - o.info.pri_res_norm) <= 1e-8 and abs(info.dua_res_norm - o.info.dua_res_norm) <= 1e-8
         assert np.array_equal(bt.ivec("active", k), o.ivec("active"))
+        # work counters written by the sweep itself: at least ceil(ranks / K) sweeps, at most one more per update call
+        assert int(s.n_sweeps) * K >= int(s.n_rank1) and int(s.n_sweeps) >= 1
+        assert 0 < int(s.sweep_entries) <= int(s.n_sweeps) * (n * (n + 1) // 2)
         o.cleanup()
 
 

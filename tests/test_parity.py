@@ -92,6 +92,52 @@ def test_reference_status_paths(ctx, golden):
     assert int(bt.info(0).status_val) == STATUS["TIME_LIMIT_REACHED"]
 
 
+def test_reference_dual_objective(ctx, golden):
+    """test_basic_qp_dual_objective / _dual_early_termination (tests/src/test_basic_qp.c:334-362): the second resident
+    factor LD_Q, compute_dual_objective on the device and the DUAL_TERMINATED exit (qpalm.c:459-468,545-583)."""
+    e = golden["expect"]["basic_qp"]
+    p = fixture_qp(golden["problems"]["basic_qp"])
+    st = gsettings(ctx, golden, "basic_qp", enable_dual_termination=1)
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    bt.solve()
+    info = bt.info(0)
+    assert int(info.status_val) == STATUS["SOLVED"]
+    for a, b in zip(bt.solution()[0][0], e["solution"]):
+        assert abs(a - b) <= abs(e["rel_tol"] * b)
+    assert abs(info.objective - info.dual_objective) <= e["dual_objective_tol"]
+    o = oracle_for(p, st)
+    o.solve()
+    assert int(info.iter) == int(o.info.iter) and int(info.iter_out) == int(o.info.iter_out)
+    assert abs(info.dual_objective - o.info.dual_objective) <= 1e-9 * max(1.0, abs(o.info.dual_objective))
+    # early termination: the limit is exceeded at the first outer update
+    st2 = dict(st, dual_objective_limit=e["dual_limit_early"])
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st2))
+    bt.solve()
+    info = bt.info(0)
+    assert int(info.status_val) == STATUS["DUAL_TERMINATED"] and int(info.iter_out) == 0
+    o = oracle_for(p, st2)
+    o.solve()
+    assert o.status_val == STATUS["DUAL_TERMINATED"] and int(info.iter) == int(o.info.iter)
+    assert abs(info.dual_objective - o.info.dual_objective) <= 1e-9 * max(1.0, abs(o.info.dual_objective))
+    assert rel(bt.solution()[0][0], o.x) <= RTOL and rel(bt.solution()[1][0], o.y) <= RTOL
+    # a batch whose members stop for different reasons + dual termination switched on by update_settings
+    q = random_qp(40, 80, seed=11, density_A=0.1, density_M=0.08)
+    stq = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    bt = QpalmBatch(ctx, [q, q], ctx.default_settings(**stq))
+    bt.solve()
+    assert bt.info(0).dual_objective == 0.0                                          # QPALM_NULL (B8)
+    assert bt.update_settings(ctx.default_settings(**dict(stq, enable_dual_termination=1))) == 0
+    bt.warm_start(None, None)
+    bt.solve()
+    o = oracle_for(q, dict(stq, enable_dual_termination=1))
+    o.solve()
+    for b in range(2):
+        info = bt.info(b)
+        assert int(info.status_val) == o.status_val == STATUS["SOLVED"] and int(info.iter) == int(o.info.iter)
+        assert abs(info.dual_objective - o.info.dual_objective) <= 1e-9 * max(1.0, abs(o.info.dual_objective))
+        assert abs(info.objective - info.dual_objective) <= 1e-4 * max(1.0, abs(info.objective))
+
+
 @pytest.mark.parametrize("over,ykey", [(dict(scaling=2, proximal=1), "warm_y_scaled"), (dict(scaling=0, proximal=1), "warm_y"),
                                        (dict(scaling=2, proximal=0), "warm_y"), (dict(scaling=0, proximal=0), "warm_y")])
 def test_reference_warm_start(ctx, golden, over, ykey):
@@ -289,6 +335,118 @@ def test_boundary_factor_update_solve_linesearch(ctx):
     assert abs(tau_g - tau_o) <= 1e-9 * max(1.0, abs(tau_o))
     assert rel(bt.vec("Qd"), o2.vec("Qd")) <= 1e-12 and rel(bt.vec("Ad"), o2.vec("Ad")) <= 1e-12
     assert np.array_equal(bt.vec("delta"), o2.vec("delta")) or rel(bt.vec("delta"), o2.vec("delta")) <= 1e-12
+
+
+def test_boundary_ldlupdate_sigma_changed(ctx):
+    """qpg_ldlupdate_sigma_changed against the oracle's ldlupdate_sigma_changed (solver_interface.c:443-503) on the
+    same factor, the same changed-row list and the same At_scale: updated factor entry by entry, At_scale and
+    At_sqrt_sigma restored as the reference leaves them."""
+    import ctypes as C
+    n, m = sizes(ctx, (70, 140), (300, 600))
+    p, st, bt, o = _prep_pair(ctx, n, m, 4321)
+    o2 = ob.OracleQP(*p.args(), settings=ob.default_settings(**dict(st, max_iter=6)))
+    o2.solve()
+    bt.iterate(6)
+    L = ob.lib()
+    ln = ob.c_int(0)
+    act = (np.arange(m) % 4 != 1).astype(np.int64)
+    pa = L.oq_get_ivec(o2.w, b"active", C.byref(ln))
+    np.ctypeslib.as_array(pa, shape=(m,))[:] = act
+    bt.set_ivec("active", act)
+    L.oq_ldlcholQAtsigmaA(o2.w)
+    bt.op("ldlcholQAtsigmaA")
+    # 19 changed rows (> one 16-rank sweep), growth factors like update_sigma produces (sqrt(mult_factor) >= 1)
+    rng = np.random.default_rng(9)
+    changed = np.sort(rng.choice(np.where(act == 1)[0], size=19, replace=False))
+    scale = np.ones(m)
+    scale[changed] = np.sqrt(1.0 + 99.0 * rng.random(19))
+    o2.vec("At_scale", copy=False)[:] = scale
+    bt.set_vec("At_scale", scale)
+    pe = L.oq_get_ivec(o2.w, b"enter", C.byref(ln))
+    np.ctypeslib.as_array(pe, shape=(m,))[:19] = changed
+    bt.set_ivec("enter", changed)
+    L.oq_set_scalar(o2.w, b"nb_sigma_changed", 19.0)
+    bt.set_scalar("nb_sigma_changed", 19)
+    Atss0 = bt.named_vec("At_sqrt_sigma", int(p.Ap[-1]))
+    L.oq_ldlupdate_sigma_changed(o2.w)
+    bt.op("ldlupdate_sigma_changed")
+    Lo, Do = o2.factor()
+    Lg, Dg = bt.factor()
+    assert rel(Dg, Do) <= 1e-10 and np.max(np.abs(np.tril(Lg, -1) - np.tril(Lo, -1))) <= 1e-9
+    assert np.array_equal(bt.vec("At_scale"), o2.vec("At_scale"))           # 1 / sqrt(1 - 1/s^2) on the changed rows
+    assert rel(bt.named_vec("At_sqrt_sigma", int(p.Ap[-1])), Atss0) <= 1e-15  # scaled by s and back by 1/s
+    # property: D grew (a positive semidefinite term was added)
+    bt.op("ldlcholQAtsigmaA")
+    assert np.all(Dg >= bt.factor()[1] * (1 - 1e-12))
+
+
+def test_boost_gamma_at_size(ctx, golden):
+    """boost_gamma + the Gershgorin pass of form_schur (iteration.c:158-211, nonconvex.c:185-210) at a size where the
+    bound spans several wavefronts: block-diagonal QPs made of perturbed copies of the reference's basic_qp (the
+    fixture on which the convex branch of qpalm.c:612-630 reaches boost_gamma; random / MPC QPs never do)."""
+    from qpalm_amd.problems import replicated_qp
+    base = fixture_qp(golden["problems"]["basic_qp"])
+    st = gsettings(ctx, golden, "basic_qp")
+    copies = sizes(ctx, 15, 60)                    # n = 60 / 240, m = 75 / 300
+    nboost = 0
+    for seed, pert in ((5, 0.01), (6, 0.1)):
+        p = replicated_qp(base, copies, seed=seed, pert=pert)
+        bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+        o = oracle_for(p, st)
+        bt.solve(); o.solve()
+        info, s = bt.info(0), bt.stats(0)
+        assert int(info.status_val) == o.status_val == STATUS["SOLVED"]
+        assert int(info.iter) == int(o.info.iter) and int(info.iter_out) == int(o.info.iter_out)
+        assert int(s.n_boost_gamma) == o.counter("n_boost_gamma")
+        assert abs(s.gamma - o.scalar("gamma")) <= 1e-9 * abs(o.scalar("gamma"))  # max(gamma_max, 1e14 / Gershgorin bound)
+        assert rel(bt.solution()[0][0], o.x) <= RTOL and rel(bt.solution()[1][0], o.y) <= RTOL
+        assert np.array_equal(bt.ivec("active"), o.ivec("active"))
+        nboost += int(s.n_boost_gamma)
+    assert nboost >= 2, "boost_gamma was not reached"
+
+
+def test_dua_inf_decision_is_a_rounding_tie(ctx, golden):
+    """dua_inf_qp, variant (proximal, scaling 2): this path declares dual infeasibility at iteration 3, the oracle at 7.
+    Q = 1e-10 I and eps_dual_inf^2 = 1e-10 make the test `dx'Q dx <= c eps^2 ||D dx||^2` (termination.c:232-235) an
+    EQUALITY in exact arithmetic, so the decision is a rounding tie.  Shown here with exact rational arithmetic on the
+    fp64 state at the deciding iteration: |lhs - rhs| is below the rounding-error bound of the expression itself."""
+    from fractions import Fraction as F
+    p = fixture_qp(golden["problems"]["dua_inf_qp"])
+    st = gsettings(ctx, golden, "dua_inf_qp", **golden["expect"]["dua_inf_qp"]["variants"][0])
+    o = oracle_for(p, st)
+    o.enable_trace(64)
+    o.solve()
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    bt.solve()
+    assert int(bt.info(0).status_val) == o.status_val == STATUS["DUAL_INFEASIBLE"]
+    # replay this path up to (not including) its deciding iteration and evaluate both sides exactly
+    it_dec = int(bt.info(0).iter)
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    bt.iterate(it_dec)
+    assert bt.num_unfinished() == 1
+    c = F(bt.stats(0).sc_c)
+    D = [F(v) for v in bt.vec("D")]
+    dx = [F(a) - F(b) for a, b in zip(bt.vec("x"), bt.vec("x_prev"))]
+    tau, gamma = F(bt.stats(0).tau), F(bt.stats(0).gamma)
+    Qdx = [F(a) - tau / gamma * F(b) for a, b in zip(bt.vec("Qd"), bt.vec("d"))]  # Qd holds tau * (Q d + d / gamma)
+    lhs = sum(a * b for a, b in zip(dx, Qdx))
+    eps2 = F(float(st.get("eps_dual_inf", 1e-5))) ** 2
+    rhs = c * eps2 * sum((a * b) ** 2 for a, b in zip(D, dx))
+    assert rhs > 0
+    # Qd is stored as tau (Q d + d / gamma) with |d / gamma| >> |Q d| (Q = 1e-10 c D^2), so forming Qd - tau/gamma d cancels:
+    # the rounding-error bound of the expression the reference evaluates is 8 eps sum |dx_j| (|Qd_j| + |tau/gamma d_j|)
+    bound = 8 * F(np.finfo(float).eps) * sum(abs(a) * (abs(F(qd)) + abs(tau / gamma * F(dd))) for a, qd, dd in zip(dx, bt.vec("Qd"), bt.vec("d")))
+    assert abs(lhs - rhs) <= bound, (float(abs(lhs - rhs)), float(bound))
+    assert bound <= F(1, 10 ** 9) * rhs  # the tie band itself is tiny: the two sides agree to 9 digits
+    # and in exact arithmetic on the PROBLEM DATA the two sides are identical: c D (1e-10 I) D  vs  c 1e-10 D^2
+    Qs = fixture_qp(golden["problems"]["dua_inf_qp"]).Qx
+    assert all(F(v) == F(1e-10) for v in Qs)
+    # iterates of the two paths agree to rounding until this path stops
+    tr = o.trace()
+    b2 = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    for k in range(it_dec):
+        b2.iterate(1)
+        assert rel(b2.vec("x"), tr["x"][k]) <= RTOL
 
 
 def test_boundary_residuals_and_active_sets_bit_exact(ctx):
