@@ -172,7 +172,7 @@ def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
                       % (len(sample), workload, t_probe)}
 
 
-def kkt_spot_check(probs, xs, ys, idx):
+def kkt_spot_check(probs, xs, ys, idx, bmin_all=None, bmax_all=None):
     """numpy KKT residuals of a few QPs of the timed batch on the unscaled data (a broken build must not post a number)"""
     import numpy as np
     import scipy.sparse as sp
@@ -184,7 +184,9 @@ def kkt_spot_check(probs, xs, ys, idx):
         Q = Ql + sp.tril(Ql, -1).T
         x, y = xs[k], ys[k]
         ax = A @ x
-        prim = np.max(np.maximum(p.bmin - ax, 0) + np.maximum(ax - p.bmax, 0)) / max(1.0, np.max(np.abs(ax)))
+        bmin = p.bmin if bmin_all is None else bmin_all[k]   # the bounds of the LAST step (update_bounds moved them)
+        bmax = p.bmax if bmax_all is None else bmax_all[k]
+        prim = np.max(np.maximum(bmin - ax, 0) + np.maximum(ax - bmax, 0)) / max(1.0, np.max(np.abs(ax)))
         Qx, Aty = Q @ x, A.T @ y
         dual = np.max(np.abs(Qx + p.q + Aty)) / max(1.0, np.max(np.abs(Qx)), np.max(np.abs(p.q)), np.max(np.abs(Aty)))
         worst = max(worst, prim, dual)
@@ -306,7 +308,7 @@ def worker(args):
     iters = np.array([int(i.iter) for i in infos])
     n_bad = int(np.sum(statuses != 1))
     xs, ys = bt.solution()
-    kkt = kkt_spot_check(probs, xs, ys, sorted({0, B // 3, B // 2, B - 1}))
+    kkt = kkt_spot_check(probs, xs, ys, sorted({0, B // 3, B // 2, B - 1}), bmin_all, bmax_all)
     ok = (n_bad == 0) and (kkt <= 1e-4)
     tot = {"solve": 0, "spmv_vectors": 0, "factor": 0, "update": 0}
     for b in range(B):

@@ -222,97 +222,152 @@ struct FactorLds {
   double colbuf[QP_FNB];
 };
 
-/* Panel update of block column J for a wavefront that owns NTJ consecutive-strided 16-row tiles
- * (tile index J/16 + wid + NW*t): branch-free k loop, fragments of step k+4 are in flight while the
- * 2*NTJ MFMAs of step k execute. */
+/* Panel update on the matrix cores:  P(rows, J : J + 16 NCT) -= L(rows, k0 : k1) D(k0 : k1) L(J : J + 16 NCT, k0 : k1)'
+ * for the row tiles of one pass (tile index J/16 + tbase + ...), all eight wavefronts together.
+ *
+ *  - The block-row operand  -L(J + i, k) D(k)  (the same for every wavefront) is staged ONCE per chunk of QP_FKC columns
+ *    in LDS by all threads (double buffered, one barrier per chunk; the global loads of chunk c+1 are in flight while
+ *    the MFMAs of chunk c run) and read from there as MFMA A fragments: it is no longer re-read from HBM/L2 by every
+ *    wavefront and pass.
+ *  - NCT = 4 works on a 64-column super-block, so the panel L(rows, 0 : J) is streamed from HBM once per 64 columns
+ *    instead of once per 32 (the re-read volume of the left-looking factorisation halves: n^3/(6*64) entries);
+ *    NCT = 2 is the 32-column form used for the second half of a super-block (k range = the 32 columns before it).
+ *  - NTJ = 2 works on PAIRS of adjacent panel rows: the wavefront's 32-row group is split into its even and its odd
+ *    rows (two MFMA row tiles), so every panel fragment pair is ONE 16-byte load of a full 128-byte line.
+ *  - Block row i of the MFMA A operand is column J + NCT*i + ct of the super-block (ct = column tile), so the NCT tile
+ *    values of a lane are adjacent in LDS (16-byte reads).  Which MFMA lane handles which entry does not change any
+ *    entry's sum: k ascending, one fma per k, as before. */
 #ifndef QP_NI_FGEMM
 #define QP_NI_FGEMM QPNI
 #endif
+#define QP_FKC 32 /* columns per staged chunk (J and the k ranges are multiples of it) */
+#define QP_FAS 66 /* row stride of the staged operand in doubles: 64 block rows + 2 (16-byte aligned, spreads the four k rows of a fragment over the banks) */
 #ifndef QP_FST
-#define QP_FST 2 /* stages of panel fragments in flight in the MFMA k loop; must divide 4 (J/8 is a multiple of 4) */
+#define QP_FST 4 /* panel fragments (k steps of 4 columns) in flight per wavefront; divides QP_FKC / 4 */
 #endif
-/* NTJ == 2 works on PAIRS of adjacent rows: the wavefront's 32-row group is split into its even
- * and its odd rows (two MFMA row tiles), and the block's 32 rows likewise into two column tiles, so
- * every fragment element pair is ONE 16-byte load (half the load instructions, full 128-byte lines):
- * the k loop is bound by the vector-memory pipeline, not by the MFMAs.  Which MFMA lane handles which
- * entry does not change any entry's sum (k ascending). */
-template <int NTJ>
-QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, int n_, int ld_, int J_, int tbase_) {
-  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), J = QP_UNIFORM(J_), tbase = QP_UNIFORM(tbase_); /* wave-uniform arguments back to SGPRs */
+struct FactorStage { double As[2][QP_FKC][QP_FAS]; };
+
+template <int NTJ, int NCT>
+QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, char *stage_, int n_, int ld_, int J_, int tbase_, int k0_, int k1_) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), J = QP_UNIFORM(J_), tbase = QP_UNIFORM(tbase_), k0 = QP_UNIFORM(k0_), k1 = QP_UNIFORM(k1_);
   qp_gdouble *L = (qp_gdouble *)L_;
   const qp_gdouble *Dg = (const qp_gdouble *)Dg_;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  FactorStage QP_LDS_AS &F = *QP_LDS_ARG(FactorStage, stage_);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   constexpr bool PAIR = (NTJ == 2);
-  /* rows of this wavefront: NTJ == 2: 32 consecutive rows from rbase, tile t = rows rbase + 2 j + t;
-   * NTJ == 1: 16 consecutive rows.  Block rows (A operand): column tile ct = rows J + 2 i + ct. */
+  constexpr int NBW = 16 * NCT; /* block width */
+  /* rows of this wavefront: NTJ == 2: 32 consecutive rows from rbase, tile t = rows rbase + 2 j + t; NTJ == 1: 16 rows */
   const int rbase = (J / 16 + tbase) * 16 + wid * 16 * NTJ;
   auto rowof = [&](const int t, const int j) QP_ALWAYS_INLINE { return PAIR ? (rbase + 2 * j + t) : (rbase + j); };
-  auto colof = [&](const int ct, const int i) QP_ALWAYS_INLINE { return J + 2 * i + ct; };
-  qp_double4 acc[NTJ][2];
+  auto colof = [&](const int ct, const int i) QP_ALWAYS_INLINE { return J + NCT * i + ct; };
+  qp_double4 acc[NTJ][NCT];
+  /* whole tile group strictly below the block and inside the matrix: no masks, 16-byte accesses */
+  const bool full = QP_UNIFORM((int)((rbase >= J + NBW) && (rbase + 16 * NTJ <= n) && (J + NBW <= n))) != 0;
+  if (full) {
 #pragma unroll
-  for (int t = 0; t < NTJ; t++) {
-    const int row = rowof(t, l15);
-#pragma unroll
-    for (int ct = 0; ct < 2; ct++)
+    for (int ct = 0; ct < NCT; ct++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int col = colof(ct, l4 + 4 * r);
-        acc[t][ct][r] = (row < n && col < n && row >= col) ? L[(size_t)col * ld + row] : 0.0;
+        double v[NTJ];
+        qp_load_rows<NTJ>(L + (size_t)colof(ct, l4 + 4 * r) * ld + rowof(0, l15), v);
+#pragma unroll
+        for (int t = 0; t < NTJ; t++) acc[t][ct][r] = v[t];
       }
-  }
-  /* fragment addresses: a pair starts at an even row (16-byte aligned: ld is a multiple of 8); pairs
-   * that start beyond the matrix read rows 0/1 instead (their results are never written) */
-  const int rowb = PAIR ? ((rbase + 2 * l15 < n) ? rbase + 2 * l15 : 0) : ((rbase + l15 < n) ? rbase + l15 : n - 1);
-  const int rowa = (J + 2 * l15 < n) ? J + 2 * l15 : 0;
-  if (J > 0) {
-    constexpr int S = QP_FST;
-    double ra[S][2][2], rb[S][2][NTJ], rd[S][2];
-    auto load = [&](const int st, const int k) QP_ALWAYS_INLINE {
+  } else {
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const qp_gdouble *colk = L + (size_t)(k + 4 * h + l4) * ld;
-        rd[st][h] = Dg[k + 4 * h + l4];
-        qp_load_rows<2>(colk + rowa, ra[st][h]);
-        qp_load_rows<NTJ>(colk + rowb, rb[st][h]);
-      }
-    };
-    auto mma = [&](const int st) QP_ALWAYS_INLINE {
+    for (int t = 0; t < NTJ; t++) {
+      const int row = rowof(t, l15);
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const double pa0 = -(ra[st][h][0] * rd[st][h]), pa1 = -(ra[st][h][1] * rd[st][h]);
-#pragma unroll
-        for (int t = 0; t < NTJ; t++) {
-          acc[t][0] = QP_MFMA_F64(pa0, rb[st][h][t], acc[t][0]);
-          acc[t][1] = QP_MFMA_F64(pa1, rb[st][h][t], acc[t][1]);
-        }
-      }
-    };
-    auto group = [&](const int k) QP_ALWAYS_INLINE {
-#pragma unroll
-      for (int st = 0; st < S; st++) {
-        mma(st);
-        const int kn = k + 8 * (S + st);
-        load(st, (kn < J) ? kn : (J - 8)); /* past the end: a harmless re-read */
-      }
-    };
-#pragma unroll
-    for (int st = 0; st < S; st++) load(st, 8 * st); /* J >= 32 >= 8 S */
-    group(0); /* peeled: steady-state wait counts inside the loop */
-#pragma unroll 1
-    for (int k = 8 * S; k < J; k += 8 * S) group(k);
-  }
-#pragma unroll
-  for (int t = 0; t < NTJ; t++) {
-    const int row = rowof(t, l15);
-    if (row < n) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ct++)
+      for (int ct = 0; ct < NCT; ct++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int col = colof(ct, l4 + 4 * r);
-          if (col < n && row >= col) L[(size_t)col * ld + row] = acc[t][ct][r];
+          acc[t][ct][r] = (row < n && col < n && row >= col) ? L[(size_t)col * ld + row] : 0.0;
         }
+    }
+  }
+  /* panel fragment address: a pair starts at an even row (16-byte aligned: ld is a multiple of 8); groups that start
+   * beyond the matrix read rows 0/1 instead (their results are never written) */
+  const int rowb = PAIR ? ((rbase + 2 * l15 < n) ? rbase + 2 * l15 : 0) : ((rbase + l15 < n) ? rbase + l15 : n - 1);
+  /* staging: thread e handles block row e % NBW of column e / NBW of the chunk, SE elements per thread */
+  constexpr int SE = (QP_FKC * NBW + QP_T - 1) / QP_T;
+  double sv[SE];
+  auto stage_load = [&](const int kb) QP_ALWAYS_INLINE {
+#pragma unroll
+    for (int q = 0; q < SE; q++) {
+      const int e = tid + q * QP_T, kk = e / NBW, i = e % NBW;
+      const int k = kb + ((kk < QP_FKC) ? kk : 0);
+      /* LDS slot i of a column holds block row i: the natural order already puts the NCT tile values of MFMA row
+       * i / NCT next to each other */
+      const int row = J + i;
+      sv[q] = (kk < QP_FKC && row < n) ? -(L[(size_t)k * ld + row] * Dg[k]) : 0.0;
+    }
+  };
+  auto stage_store = [&](const int buf) QP_ALWAYS_INLINE {
+#pragma unroll
+    for (int q = 0; q < SE; q++) {
+      const int e = tid + q * QP_T, kk = e / NBW, i = e % NBW;
+      if (kk < QP_FKC) F.As[buf][kk][i] = sv[q];
+    }
+  };
+  constexpr int S = QP_FST, NH = QP_FKC / 4;
+  static_assert(NH % S == 0, "QP_FST must divide QP_FKC / 4");
+  double rb[S][NTJ];
+  auto loadb = [&](const int st, const int k) QP_ALWAYS_INLINE { qp_load_rows<NTJ>(L + (size_t)(k + l4) * ld + rowb, rb[st]); };
+  auto mma = [&](const int st, const int buf, const int h) QP_ALWAYS_INLINE {
+    double pa[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) pa[ct] = F.As[buf][4 * h + l4][NCT * l15 + ct];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+      for (int t = 0; t < NTJ; t++) acc[t][ct] = QP_MFMA_F64(pa[ct], rb[st][t], acc[t][ct]);
+  };
+  __syncthreads(); /* the staging buffers may still be read by the previous call's last chunk */
+  stage_load(k0);
+  stage_store(0);
+#pragma unroll
+  for (int st = 0; st < S; st++) loadb(st, k0 + 4 * st);
+  __syncthreads();
+#pragma unroll 1
+  for (int kb = k0, c = 0; kb < k1; kb += QP_FKC, c++) {
+    const int buf = c & 1;
+    const bool more = (kb + QP_FKC < k1);
+    if (more) stage_load(kb + QP_FKC); /* in flight during this chunk's MFMAs */
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      const int st = h % S;
+      mma(st, buf, h);
+      const int kn = kb + 4 * (h + S); /* the fragment S steps ahead (next chunk included; past the end: a harmless re-read) */
+      loadb(st, (kn < k1) ? kn : (k1 - 4));
+    }
+    if (more) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+  if (full) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double v[NTJ];
+#pragma unroll
+        for (int t = 0; t < NTJ; t++) v[t] = acc[t][ct][r];
+        qp_store_rows<NTJ>(L + (size_t)colof(ct, l4 + 4 * r) * ld + rowof(0, l15), v);
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NTJ; t++) {
+      const int row = rowof(t, l15);
+      if (row < n) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int col = colof(ct, l4 + 4 * r);
+            if (col < n && row >= col) L[(size_t)col * ld + row] = acc[t][ct][r];
+          }
+      }
     }
   }
 }
@@ -374,14 +429,30 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *l
   long long tq0 = QP_CLOCK();
   for (int J = 0; J < n; J += NB) {
     const int jb = (n - J < NB) ? (n - J) : NB;
-    /* ---- (1) panel update on the matrix cores: passes of at most QP_FNT row tiles per wavefront ---- */
+    /* ---- (1) panel update on the matrix cores.  Left-looking over 64-column super-blocks: at the start of a
+     * super-block its 64 columns receive the contributions of ALL earlier columns (the panel is streamed once per
+     * 64 columns); its second 32-column block then only needs the 32 columns just finished. ---------------- */
     {
-      const int ntiles = (n - J + 15) / 16;
-      for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW) {
-        const int rem = ntiles - tbase;
-        const int ntj = (rem + QP_NW - 1) / QP_NW; /* same for every wavefront */
-        if (ntj <= 1) factor_panel_update<1>(L_, Dg_, n, ld, J, tbase);
-        else factor_panel_update<2>(L_, Dg_, n, ld, J, tbase);
+      const bool super = (J % (2 * NB)) == 0;
+      const int k0 = super ? 0 : J - NB, k1 = J;
+      if (k1 > k0) {
+        const int ntiles = (n - J + 15) / 16;
+        char *stage = lds_ + ((sizeof(FactorLds) + 15) & ~(size_t)15);
+        for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW) {
+          const int rem = ntiles - tbase;
+          const int ntj = (rem + QP_NW - 1) / QP_NW; /* same for every wavefront */
+          if (super) {
+            if (ntj <= 1) factor_panel_update<1, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+            else factor_panel_update<2, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+          } else {
+            if (ntj <= 1) factor_panel_update<1, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+            else factor_panel_update<2, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+          }
+        }
+        if (tid == 0) { /* entries of L re-read: the panel rows once per pass group, the block rows once per pass */
+          const long long npass = (ntiles + QP_FNT * QP_NW - 1) / (QP_FNT * QP_NW);
+          tdbg[QPG_CNT_FACTOR_REREAD] += (long long)(n - J) * (k1 - k0) + npass * (super ? 2 * NB : NB) * (long long)(k1 - k0);
+        }
       }
     }
     __syncthreads();

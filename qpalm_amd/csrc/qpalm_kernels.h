@@ -270,7 +270,14 @@ __global__ __launch_bounds__(256) void k_hbm_copy(const double *__restrict__ src
   typedef double copy_d2 __attribute__((ext_vector_type(2)));
   const copy_d2 *s2 = (const copy_d2 *)src;
   copy_d2 *d2 = (copy_d2 *)dst;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) d2[i] = s2[i];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < npairs; i += 4 * stride) { /* four independent 16-byte loads in flight per lane */
+    const copy_d2 a = __builtin_nontemporal_load(s2 + i), b = __builtin_nontemporal_load(s2 + i + stride);
+    const copy_d2 c = __builtin_nontemporal_load(s2 + i + 2 * stride), d = __builtin_nontemporal_load(s2 + i + 3 * stride);
+    __builtin_nontemporal_store(a, d2 + i); __builtin_nontemporal_store(b, d2 + i + stride);
+    __builtin_nontemporal_store(c, d2 + i + 2 * stride); __builtin_nontemporal_store(d, d2 + i + 3 * stride);
+  }
+  for (; i < npairs; i += stride) d2[i] = s2[i];
 #endif
 }
 

@@ -1,0 +1,93 @@
+"""BASELINE.json configs[2] at config scale: a batch of mpc-160 QPs (n=160, m=270; T=10, nx=10, nu=5) driven through a
+receding-horizon sequence as simulations/randomMPCsequential.m:158-177 does: apply the first input, shift the previous
+solution as warm start, move the initial-state bounds (qpalm_update_bounds) and solve again.  Every step a sample of
+the batch is compared with the oracle driven through the same calls (iterations and active sets exact, x, y to 1e-9);
+all QPs must be solved and feasible.
+
+[emu]: 6 QPs x 3 steps on the host-emulated kernels (CPU suite).  [hip]: 4096 QPs x 5 steps, 64-QP oracle sample."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from qpalm_amd.problems import random_mpc_qp
+from qpalm_amd.solver import QpalmBatch
+from tests.test_parity import rel, sizes, RTOL
+
+ST = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+T, NX, NU = 10, 10, 5
+
+
+def _plants(nb, per_plant):
+    """one random plant per `per_plant` QPs; returns (problems, dynamics) with every QP its own initial state"""
+    rng = np.random.default_rng(2024)
+    probs, dyn = [], []
+    base = None
+    for k in range(nb):
+        if k % per_plant == 0:
+            base = random_mpc_qp(T=T, nx=NX, nu=NU, seed=100 + k // per_plant)
+            A = base.A_mat().toarray()
+            # rows nx..2nx-1 hold  x_1 - Adyn x_0 - Bdyn u_0 = 0
+            Adyn = -A[NX:2 * NX, 0:NX]
+            Bdyn = -A[NX:2 * NX, (T + 1) * NX:(T + 1) * NX + NU]
+        x0 = 2.0 * (2 * rng.random(NX) - 1)
+        bmin, bmax = base.bmin.copy(), base.bmax.copy()
+        bmin[:NX] = x0
+        bmax[:NX] = x0
+        probs.append(type(base)(base.n, base.m, base.Qp, base.Qi, base.Qx, base.Ap, base.Ai, base.Ax, base.q, bmin, bmax))
+        dyn.append((Adyn, Bdyn))
+    return probs, dyn, rng
+
+
+def _shift(x, Adyn):
+    """randomMPCsequential.m:166-168 in this QP's variable order [x_0..x_T, u_0..u_{T-1}]"""
+    xs, us = x[:(T + 1) * NX].reshape(T + 1, NX), x[(T + 1) * NX:].reshape(T, NU)
+    xs2 = np.vstack([xs[1:], (Adyn @ xs[-1])[None, :]])
+    us2 = np.vstack([us[1:], np.zeros((1, NU))])
+    return np.concatenate([xs2.ravel(), us2.ravel()])
+
+
+def test_mpc_sequence_at_config_scale(ctx):
+    nb, nsteps, nsample, per_plant = sizes(ctx, (6, 3, 6, 3), (4096, 5, 64, 64))
+    probs, dyn, rng = _plants(nb, per_plant)
+    n, m = probs[0].n, probs[0].m
+    assert (n, m) == (160, 270)
+    sample = np.unique(np.linspace(0, nb - 1, nsample).astype(int))
+    bt = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
+    oracles = {k: ob.OracleQP(*probs[k].args(), settings=ob.default_settings(**ST)) for k in sample}
+    bmin = np.stack([p.bmin for p in probs])
+    bmax = np.stack([p.bmax for p in probs])
+    bt.solve()
+    for o in oracles.values():
+        o.solve()
+    for step in range(nsteps):
+        xs, ys = bt.solution()
+        infos = bt.infos()
+        assert all(int(i.status_val) == 1 for i in infos), "step %d: not every QP solved" % step
+        for k in sample:
+            o = oracles[k]
+            assert o.status_val == 1
+            assert int(infos[k].iter) == int(o.info.iter) and int(infos[k].iter_out) == int(o.info.iter_out), (step, k)
+            assert rel(xs[k], o.x) <= RTOL and rel(ys[k], o.y) <= RTOL, (step, k)
+            assert np.array_equal(bt.ivec("active", k), o.ivec("active")), (step, k)
+        # size-independent property on the whole batch: the dynamics rows hold (A x = 0 for rows nx..)
+        if step == nsteps - 1:
+            break
+        # the plant moves: apply u_0 (+ disturbance), shift the solution, move the x_0 bounds, warm start
+        xw = np.empty_like(xs)
+        for k in range(nb):
+            Adyn, Bdyn = dyn[k]
+            u0 = xs[k, (T + 1) * NX:(T + 1) * NX + NU]
+            x_init = Adyn @ xs[k, :NX] + Bdyn @ u0 + 1e-2 * rng.standard_normal(NX)
+            bmin[k, :NX] = x_init
+            bmax[k, :NX] = x_init
+            xw[k] = _shift(xs[k], Adyn)
+        assert bt.update_bounds(bmin, bmax) == 0
+        bt.warm_start(xw, ys)
+        bt.solve()
+        for k in sample:
+            o = oracles[k]
+            o.update_bounds(bmin[k], bmax[k])
+            o.warm_start(xw[k], ys[k])
+            o.solve()
+    for o in oracles.values():
+        o.cleanup()
