@@ -71,6 +71,15 @@ struct oq_workspace {
   oq_int nb_active, nb_enter, nb_leave;
   int reset_newton;
   oq_factor LD, LD_Q;
+  /* KKT path (LADEL build, FACTORIZE_KKT; src/solver_interface.c:119-247, src/newton.c:22-95) */
+  int kkt_mode;            /* solver->factorization_method == FACTORIZE_KKT */
+  int first_factorization; /* types.h:176 */
+  oq_factor LDK;           /* dense LDL' of the (n+m) KKT matrix, natural order */
+  oq_int *kkt_state;       /* per constraint: 0 unit diagonal (inactive at the last (re)form), 1 active row present,
+                              2 deleted by row_del (diagonal -1/sigma kept for the refinement mat-vec, :233-235) */
+  oq_float *rhs_kkt, *sol_kkt, *kkt_tmp;
+  oq_sparse At;            /* transpose of the (scaled) A: row k of A = column k (solver->At, qpalm.c:250) */
+  oq_int n_row_add, n_row_del, n_refine;
   oq_float *Hbuf; /* scratch n*n for forming Q + A'SA */
   oq_float *wbuf; /* scratch n for rank-1 vectors */
   /* settings / solution / info */
@@ -455,6 +464,15 @@ oq_workspace *oq_setup(oq_int n_, oq_int m_, const oq_int *Qp, const oq_int *Qi,
   w->enter = izalloc(m); w->leave = izalloc(m);
   w->neg_dphi = zalloc(n); w->d = zalloc(n); w->Qd = zalloc(n); w->Ad = zalloc(m); w->yh = zalloc(m); w->Atyh = zalloc(n);
   w->At_scale = zalloc(m);
+  /* qpalm_set_factorization_method (solver_interface.c:20-75): the CHOLMOD build forces SCHUR (:72-74); under LADEL
+   * the setting is honoured and KKT_OR_SCHUR applies an nnz-based rule.  The oracle takes KKT only when it is asked
+   * for explicitly (FACTORIZE_KKT = 0); KKT_OR_SCHUR (2) keeps the CHOLMOD build's answer. */
+  w->kkt_mode = (settings->factorization_method == 0);
+  w->first_factorization = 1; /* qpalm.c:272 (set under USE_LADEL only; only the KKT path reads it here) */
+  if (w->kkt_mode) {
+    w->kkt_state = izalloc(m);
+    w->rhs_kkt = zalloc(n + m); w->sol_kkt = zalloc(n + m); w->kkt_tmp = zalloc(n + m);
+  }
   /* nonconvex (set_settings_nonconvex, nonconvex.c:171-183) is a next-tier row */
   w->sol_x = zalloc(n); w->sol_y = zalloc(m);
   update_status(&w->info, OQ_UNSOLVED);
@@ -475,7 +493,9 @@ void oq_cleanup(oq_workspace *w) {
   for (size_t k = 0; k < sizeof(fv) / sizeof(fv[0]); k++) { free(*fv[k]); *fv[k] = NULL; }
   free(w->s); free(w->index_L); free(w->index_P); free(w->index_J);
   free(w->active); free(w->active_old); free(w->enter); free(w->leave);
-  factor_free(&w->LD); factor_free(&w->LD_Q);
+  factor_free(&w->LD); factor_free(&w->LD_Q); factor_free(&w->LDK);
+  free(w->kkt_state); free(w->rhs_kkt); free(w->sol_kkt); free(w->kkt_tmp);
+  if (w->At.p) sp_free(&w->At);
   free(w);
 }
 
@@ -578,6 +598,16 @@ void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
   }
   sp_scale_col(&w->At_sqrt_sigma, w->At_scale);
   /* first_factorization exists only under USE_LADEL; the CHOLMOD branch reads the calloc'ed 0 */
+  if (w->kkt_mode) {
+    /* iteration.c:135-144 under FACTORIZE_KKT: either branch ends in reset_newton = TRUE.  The rank-1 path
+     * (solver_interface.c:463-481) updates the factor at row pinv[row] -- a VARIABLE's row, not the constraint's --
+     * and then forces reset_newton, so the next Newton step refactorises and the update has no effect on any iterate;
+     * it is not restated. */
+    if (w->first_factorization || (st->proximal && w->gamma < st->gamma_max) || w->nb_sigma_changed > 0 ||
+        (w->nb_sigma_changed > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), 0.25 * st->max_rank_update)))
+      w->reset_newton = 1;
+    return;
+  }
   if ((st->proximal && w->gamma < st->gamma_max) ||
       (w->nb_sigma_changed > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), 0.25 * st->max_rank_update))) {
     w->reset_newton = 1;
@@ -635,7 +665,8 @@ static void boost_gamma(oq_workspace *w) { /* iteration.c:158-211 */
   if (w->nb_active) {
     oq_int nb = 0;
     for (oq_int i = 0; i < w->m; i++) if (w->active[i]) w->enter[nb++] = i; /* B4 */
-    w->gamma = OQ_MAX(w->settings.gamma_max, 1e14 / gershgorin_max_AtsigmaA(w, w->enter, nb));
+    if (w->kkt_mode) w->gamma = 1e10; /* iteration.c:173-176 */
+    else w->gamma = OQ_MAX(w->settings.gamma_max, 1e14 / gershgorin_max_AtsigmaA(w, w->enter, nb));
     w->gamma_maxed = 1;
   } else w->gamma = 1e12;
   if (prev != w->gamma) {
@@ -733,10 +764,158 @@ void oq_set_entering_leaving_constraints(oq_workspace *w) { /* newton.c:134-149 
   }
   w->nb_enter = ne; w->nb_leave = nl;
 }
+
+/* =========================================================================================
+ * KKT path: qpalm_form_kkt / qpalm_reform_kkt, kkt_update_entering / leaving_constraints, kkt_solve
+ * (src/solver_interface.c:119-247) and the KKT branch of newton_set_direction with its iterative refinement
+ * (src/newton.c:22-95).  LADEL (github.com/Benny44/LADEL, branch master, SHA unpinned, .gitmodules:9-12) is absent from
+ * the reference tree; its arithmetic is restated from the published algorithms on a DENSE (n+m) x (n+m) lower
+ * triangle in natural order (LADEL's default AMD ordering only permutes the same quasi-definite system):
+ *   - ladel_factorize(_advanced / _with_prior_basis)_with_diag : LDL' without pivoting of K + diag(1/gamma on the first n);
+ *   - ladel_row_add / ladel_row_del : Davis & Hager, "Row modifications of a sparse Cholesky factorization"
+ *     (SIAM J. Matrix Anal. Appl. 2005): with K = [K11 k12 K31'; k12' k22 k32'; K31 k32 K33] and row p = n+k,
+ *       add:  L11 z = k12, l12 = D11^{-1} z, d22 = k22 - l12' z, l32 = (k32 - L31 z) / d22,
+ *             L33 D33 L33' <- L33 D33 L33' - l32 d22 l32'   (a rank-1 update: d22 < 0 for a constraint row);
+ *       del:  L33 D33 L33' <- L33 D33 L33' + l32 d22 l32',  l12 = 0, l32 = 0, d22 = 1;
+ *   - ladel_dense_solve : L y = b, y /= D, L' x = y.
+ * "parity unpinned": the reference's tests pin this path only through end-to-end solutions (tests/src/test_basic_qp.c
+ * etc. run under the LADEL build, which CI uses: travis/buildTest.sh:48).
+ * ======================================================================================= */
+static void kkt_form_and_factor(oq_workspace *w) {
+  const oq_int n = w->n, m = w->m, np = n + m;
+  if (w->At.p) sp_free(&w->At);
+  sp_transpose(&w->A, &w->At); /* n x m: column k = row k of the scaled A */
+  factor_alloc(&w->LDK, np);
+  oq_float *K = w->LDK.L;
+  memset(K, 0, (size_t)np * (size_t)np * sizeof(oq_float));
+  const oq_sparse *Q = &w->Q;
+  for (oq_int j = 0; j < n; j++)
+    for (oq_int k = Q->p[j]; k < Q->p[j + 1]; k++) { const oq_int i = Q->i[k]; if (i >= j) K[i + j * np] += Q->x[k]; }
+  if (w->settings.proximal) for (oq_int j = 0; j < n; j++) K[j + j * np] += 1.0 / w->gamma; /* ladel_diag, newton.c:27-30 */
+  for (oq_int k = 0; k < m; k++) {
+    const oq_int p = n + k, cnt = w->At.p[k + 1] - w->At.p[k];
+    if (w->active[k]) {
+      w->kkt_state[k] = 1;
+      for (oq_int e = w->At.p[k]; e < w->At.p[k + 1]; e++) K[p + w->At.i[e] * np] = w->At.x[e];
+      K[p + p * np] = cnt ? -w->sigma_inv[k] : 1.0; /* empty rows of A get a unit diagonal (:169) */
+    } else { w->kkt_state[k] = 0; K[p + p * np] = 1.0; }
+  }
+  oq_dense_ldl_factor(np, K, np, w->LDK.D);
+  w->LDK.valid = 1;
+}
+
+static void kkt_row_add(oq_workspace *w, oq_int k) { /* ladel_row_add(LD, sym, n+k, kkt, n+k, -sigma_inv[k], c), :209-217 */
+  const oq_int n = w->n, np = w->n + w->m, p = n + k;
+  oq_float *L = w->LDK.L, *D = w->LDK.D, *z = w->kkt_tmp;
+  for (oq_int j = 0; j < np; j++) z[j] = 0.0;
+  for (oq_int e = w->At.p[k]; e < w->At.p[k + 1]; e++) z[w->At.i[e]] = w->At.x[e];
+  for (oq_int j = 0; j < p; j++) { /* L11 z = k12, column oriented */
+    const oq_float zj = z[j];
+    if (zj == 0.0) continue;
+    const oq_float *Lj = L + j * np;
+    for (oq_int i = j + 1; i < p; i++) z[i] -= Lj[i] * zj;
+  }
+  oq_float d22 = -w->sigma_inv[k];
+  for (oq_int j = 0; j < p; j++) { const oq_float l = z[j] / D[j]; d22 -= l * z[j]; L[p + j * np] = l; }
+  oq_float *wv = w->rhs_kkt; /* scratch: the caller overwrites rhs_kkt afterwards */
+  const oq_float sq = sqrt(OQ_ABS(d22));
+  for (oq_int i = p + 1; i < np; i++) { /* l32 = -(L31 z) / d22  (k32 = 0: constraint rows do not couple) */
+    oq_float acc = 0.0;
+    for (oq_int j = 0; j < p; j++) acc += L[i + j * np] * z[j];
+    const oq_float l = -acc / d22;
+    L[i + p * np] = l;
+    wv[i] = sq * l;
+  }
+  D[p] = d22;
+  if (p + 1 < np) oq_dense_ldl_rank1(np - p - 1, L + (p + 1) + (p + 1) * np, np, D + p + 1, wv + p + 1, d22 < 0);
+  w->kkt_state[k] = 1;
+  w->n_row_add++;
+}
+
+static void kkt_row_del(oq_workspace *w, oq_int k) { /* ladel_row_del(LD, sym, n+k, c), :229 */
+  const oq_int np = w->n + w->m, p = w->n + k;
+  oq_float *L = w->LDK.L, *D = w->LDK.D, *wv = w->rhs_kkt;
+  const oq_float d = D[p], sq = sqrt(OQ_ABS(d));
+  for (oq_int i = p + 1; i < np; i++) { wv[i] = sq * L[i + p * np]; L[i + p * np] = 0.0; }
+  for (oq_int j = 0; j < p; j++) L[p + j * np] = 0.0;
+  D[p] = 1.0;
+  if (p + 1 < np) oq_dense_ldl_rank1(np - p - 1, L + (p + 1) + (p + 1) * np, np, D + p + 1, wv + p + 1, d > 0);
+  w->kkt_state[k] = 2;
+  w->n_row_del++;
+}
+
+/* mat_vec(kkt, x, y) (+ the proximal diagonal added by hand, newton.c:58-59): kkt as the reference stores it, i.e.
+ * columns truncated by nz[]: state 0 -> unit diagonal, 1 -> [A(k,:)'; -1/sigma_k], 2 -> diagonal -1/sigma_k only */
+static void kkt_matvec(oq_workspace *w, const oq_float *x, oq_float *y) {
+  const oq_int n = w->n, m = w->m;
+  oq_mat_vec(&w->Q, x, y);
+  if (w->settings.proximal) for (oq_int j = 0; j < n; j++) y[j] = 1 * y[j] + (1.0 / w->gamma) * x[j];
+  for (oq_int k = 0; k < m; k++) {
+    const oq_float xk = x[n + k];
+    if (w->kkt_state[k] == 1) {
+      oq_float acc = 0.0;
+      for (oq_int e = w->At.p[k]; e < w->At.p[k + 1]; e++) { acc += w->At.x[e] * x[w->At.i[e]]; y[w->At.i[e]] += w->At.x[e] * xk; }
+      const oq_int cnt = w->At.p[k + 1] - w->At.p[k];
+      y[n + k] = acc + (cnt ? -w->sigma_inv[k] : 1.0) * xk;
+    } else if (w->kkt_state[k] == 2) y[n + k] = -w->sigma_inv[k] * xk;
+    else y[n + k] = xk;
+  }
+}
+
+static void kkt_newton_direction(oq_workspace *w) { /* newton.c:22-95 */
+  const oq_settings *st = &w->settings;
+  const oq_int n = w->n, m = w->m, np = n + m;
+  if (w->first_factorization) {
+    kkt_form_and_factor(w); w->first_factorization = 0; w->n_refactor++; w->last_fact = 1;
+  } else if (w->reset_newton ||
+             (w->nb_enter + w->nb_leave) > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), st->max_rank_update)) {
+    kkt_form_and_factor(w); w->n_refactor++; w->last_fact = 1;
+  } else {
+    w->last_fact = 0;
+    for (oq_int e = 0; e < w->nb_enter; e++) { kkt_row_add(w, w->enter[e]); w->last_fact = 2; }
+    for (oq_int e = 0; e < w->nb_leave; e++) { kkt_row_del(w, w->leave[e]); w->last_fact = 2; }
+  }
+  /* kkt_solve, solver_interface.c:238-247 */
+  for (oq_int j = 0; j < n; j++) w->rhs_kkt[j] = w->dphi[j] * -1;
+  for (oq_int k = 0; k < m; k++) w->rhs_kkt[n + k] = 0;
+  vec_cp(w->rhs_kkt, w->sol_kkt, (size_t)np);
+  oq_dense_ldl_solve(np, w->LDK.L, np, w->LDK.D, w->sol_kkt);
+  vec_cp(w->sol_kkt, w->d, (size_t)n);
+  w->n_solve++;
+  /* iterative refinement, newton.c:57-90 (constants.h:101-103) */
+  kkt_matvec(w, w->sol_kkt, w->rhs_kkt);
+  oq_vec_self_mult_scalar(w->rhs_kkt, -1, (size_t)np);
+  const oq_float ref_norm = OQ_MAX(oq_vec_norm_inf(w->rhs_kkt, (size_t)np), oq_vec_norm_inf(w->dphi, (size_t)n));
+  oq_vec_mult_add_scaled(w->rhs_kkt, w->dphi, 1, -1, (size_t)n);
+  oq_float res = oq_vec_norm_inf(w->rhs_kkt, (size_t)np);
+  oq_int k = 0;
+  while (k < 3 && res > OQ_MAX(1e-10 * ref_norm, 1e-12)) {
+    k++;
+    vec_cp(w->sol_kkt, w->temp_n, (size_t)n);
+    vec_cp(w->sol_kkt + n, w->temp_m, (size_t)m);
+    vec_cp(w->rhs_kkt, w->sol_kkt, (size_t)np);
+    oq_dense_ldl_solve(np, w->LDK.L, np, w->LDK.D, w->sol_kkt);
+    oq_vec_add_scaled(w->sol_kkt, w->d, w->d, 1, (size_t)n);
+    oq_vec_mult_add_scaled(w->sol_kkt, w->temp_n, 1, 1, (size_t)n);
+    oq_vec_mult_add_scaled(w->sol_kkt + n, w->temp_m, 1, 1, (size_t)m);
+    kkt_matvec(w, w->sol_kkt, w->rhs_kkt);
+    oq_vec_self_mult_scalar(w->rhs_kkt, -1, (size_t)np);
+    oq_vec_mult_add_scaled(w->rhs_kkt, w->dphi, 1, -1, (size_t)n);
+    res = oq_vec_norm_inf(w->rhs_kkt, (size_t)np);
+    w->n_refine++;
+  }
+}
+
 void oq_newton_set_direction(oq_workspace *w) { /* newton.c:17-120 */
   const oq_settings *st = &w->settings;
   oq_set_active_constraints(w);
   oq_set_entering_leaving_constraints(w);
+  if (w->kkt_mode) {
+    kkt_newton_direction(w);
+    ivec_cp(w->active, w->active_old, (size_t)w->m);
+    w->reset_newton = 0;
+    return;
+  }
   if ((w->reset_newton && w->nb_active) ||
       (w->nb_enter + w->nb_leave) > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), st->max_rank_update)) {
     oq_ldlcholQAtsigmaA(w); w->n_refactor++; w->last_fact = 1;
@@ -1120,6 +1299,7 @@ void oq_update_settings(oq_workspace *w, const oq_settings *s) { /* qpalm.c:739-
   if (!validate_settings(s)) { update_status(&w->info, OQ_ERROR); return; }
   if (w->settings.scaling > s->scaling) { update_status(&w->info, OQ_ERROR); return; }
   else if (w->settings.scaling < s->scaling) {
+    w->first_factorization = 1; /* qpalm.c:774 (USE_LADEL) */
     size_t n = (size_t)w->n, m = (size_t)w->m;
     if (!w->has_scaling) { /* the reference would dereference a NULL scaling struct here */
       w->has_scaling = 1; w->D = zalloc(n); w->Dinv = zalloc(n); w->E = zalloc(m); w->Einv = zalloc(m);
@@ -1240,6 +1420,10 @@ oq_int oq_get_counter(const oq_workspace *w, const char *name) {
   if (!strcmp(name, "n_solve")) return w->n_solve;
   if (!strcmp(name, "n_sigma_updates")) return w->n_sigma_updates;
   if (!strcmp(name, "n_boost_gamma")) return w->n_boost_gamma;
+  if (!strcmp(name, "n_row_add")) return w->n_row_add;
+  if (!strcmp(name, "n_row_del")) return w->n_row_del;
+  if (!strcmp(name, "n_refine")) return w->n_refine;
+  if (!strcmp(name, "kkt_mode")) return w->kkt_mode;
   if (!strcmp(name, "nb_active")) return w->nb_active;
   if (!strcmp(name, "nb_enter")) return w->nb_enter;
   if (!strcmp(name, "nb_leave")) return w->nb_leave;

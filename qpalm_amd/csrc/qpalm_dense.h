@@ -522,8 +522,10 @@ struct SolveLds {
 #ifndef QP_NI_SOLVE
 #define QP_NI_SOLVE QPNI
 #endif
-QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld_, double *xg_, char *lds_, int lds_bytes, int64_t *tdbg_ = nullptr) {
-  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_); /* wave-uniform arguments back to SGPRs */
+/* fwd_only != 0: only L y = b on the leading n x n block (n may be smaller than the panel), y returned unscaled:
+ * the first step of a KKT row addition (L11 z = k12, Davis & Hager 2005) */
+QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld_, double *xg_, char *lds_, int lds_bytes, int64_t *tdbg_ = nullptr, int fwd_only_ = 0) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), fwd_only = QP_UNIFORM(fwd_only_); /* wave-uniform arguments back to SGPRs */
   int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* null or the timers in the kernel's static LDS */
   const qp_gdouble *L = (const qp_gdouble *)L_, *Dg = (const qp_gdouble *)Dg_;
   qp_gdouble *xg = (qp_gdouble *)xg_;
@@ -593,6 +595,11 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
     if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[9] += t - ts0; ts0 = t; }
   }
   __syncthreads();
+  if (fwd_only) {
+    for (int i = tid; i < n; i += QP_T) xg[i] = xs[i];
+    __syncthreads();
+    return;
+  }
   for (int i = tid; i < n; i += QP_T) xs[i] = xs[i] / Dg[i];
   __syncthreads();
   /* backward: L' x = z */
@@ -733,10 +740,13 @@ template <int RPT, int K>
 /* a real function (own register allocation, see qpalm_device.h): plain pointer arguments, re-typed inside */
 QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *Atss_, const int n_, const int ld_,
                                double *L_, double *Dg_, double *Wst_, const int *cols_, int n_up_,
-                               const int *cols_dn_, int n_dn_, QpShared *S_, char *lds, int64_t *tdbg_) {
+                               const int *cols_dn_, int n_dn_, QpShared *S_, char *lds, int64_t *tdbg_, int pre_jmin_ = -1) {
   /* arguments of a real function arrive in VGPRs; these are wave-uniform: back to SGPRs, so that the
    * loops they bound are scalar loops (not exec-mask loops) and v_readlane indices are scalars */
   const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), n_up = QP_UNIFORM(n_up_), n_dn = QP_UNIFORM(n_dn_);
+  /* pre_jmin >= 0: ONE rank whose dense vector the caller has already written to Wst[0 .. n) (first nonzero at
+   * pre_jmin), sign +1 if n_up == 1 else -1: the trailing update of a KKT row addition / deletion */
+  const int pre_jmin = QP_UNIFORM(pre_jmin_);
   int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* the timers live in the kernel's static LDS */
   const qp_gint *Atp = (const qp_gint *)Atp_, *Ati = (const qp_gint *)Ati_, *cols = (const qp_gint *)cols_, *cols_dn = (const qp_gint *)cols_dn_;
   const qp_gdouble *Atss = (const qp_gdouble *)Atss_;
@@ -753,18 +763,20 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
     const int kk = (nr - r0 < K) ? (nr - r0) : K;
     __syncthreads();
     long long tq0 = QP_CLOCK();
-    for (int e = tid; e < kk * n; e += QP_T) Wst[e] = 0.0;
-    __syncthreads();
     int jmin = n;
-    for (int r = wid; r < kk; r += QP_NW) {
-      const int g = r0 + r;
-      const int t = (g < n_up) ? cols[g] : cols_dn[g - n_up];
-      for (int k = Atp[t] + lane; k < Atp[t + 1]; k += 64) {
-        const int i = Ati[k];
-        Wst[(size_t)r * n + i] = Atss[k];
-        jmin = (i < jmin) ? i : jmin;
+    if (pre_jmin < 0) {
+      for (int e = tid; e < kk * n; e += QP_T) Wst[e] = 0.0;
+      __syncthreads();
+      for (int r = wid; r < kk; r += QP_NW) {
+        const int g = r0 + r;
+        const int t = (g < n_up) ? cols[g] : cols_dn[g - n_up];
+        for (int k = Atp[t] + lane; k < Atp[t + 1]; k += 64) {
+          const int i = Ati[k];
+          Wst[(size_t)r * n + i] = Atss[k];
+          jmin = (i < jmin) ? i : jmin;
+        }
       }
-    }
+    } else jmin = (pre_jmin < n) ? pre_jmin : n - 1;
     jmin = QP_UNIFORM(block_imin(S, jmin)); /* same value in every lane: keep the block loops scalar */
     double w[RPT][K];
 #pragma unroll

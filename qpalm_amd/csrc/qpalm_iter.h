@@ -313,6 +313,14 @@ QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
   __syncthreads();
   const double thr = qmin(st.max_rank_update_fraction * (double)(n + m), 0.25 * (double)st.max_rank_update);
   int nupd = 0;
+  if (V.kkt) {
+    /* FACTORIZE_KKT (iteration.c:135-144, solver_interface.c:463-481): every branch that changes anything ends in
+     * reset_newton = TRUE; the reference's rank-1 correction is applied at row pinv[row] (a variable's row) and is
+     * overwritten by the refactorisation that reset_newton forces, so it is not restated */
+    if (I.s.kkt_first || (st.proximal && I.s.gamma < st.gamma_max) || nchg > 0) { if (tid == 0) I.s.reset_newton = 1; }
+    __syncthreads();
+    return 0;
+  }
   if ((st.proximal && I.s.gamma < st.gamma_max) || ((double)nchg > thr)) {
     if (tid == 0) I.s.reset_newton = 1;
   } else if (nchg == 0) {
@@ -374,7 +382,7 @@ QPN void dev_boost_gamma_apply(const qpg_view &V, const QpArrays &a, IterShared 
   const double prev = I.s.gamma;
   double g;
   if (I.s.nb_active) {
-    g = qmax(st.gamma_max, 1e14 / ub);
+    g = V.kkt ? 1e10 : qmax(st.gamma_max, 1e14 / ub); /* iteration.c:173-176 under FACTORIZE_KKT */
     if (threadIdx.x == 0) I.s.gamma_maxed = 1;
   } else g = 1e12;
   __syncthreads();
@@ -561,6 +569,8 @@ QPN double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const
   return dobj;
 }
 
+#include "qpalm_kkt.h"
+
 /* =============================================================================================
  * the loop body of qpalm_solve (src/qpalm.c:484-711) for one QP; runs at most `budget` iterations
  * =========================================================================================== */
@@ -569,8 +579,8 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
   const qpg_settings &st = *V.settings;
   QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x;
-  double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * V.wst_stride;
-  double *LQ = V.LQ ? V.LQ + (size_t)slot * V.ld * n : nullptr, *DgQ = V.DgQ ? V.DgQ + (size_t)slot * n : nullptr;
+  double *L = V.L + (size_t)slot * V.ld * V.nfac, *Dg = V.Dg + (size_t)slot * V.nfac, *Wst = V.Wst + (size_t)slot * V.wst_stride;
+  double *LQ = V.LQ ? V.LQ + (size_t)slot * V.ld * V.nfac : nullptr, *DgQ = V.DgQ ? V.DgQ + (size_t)slot * V.nfac : nullptr;
   __syncthreads();
   if (tid == 0) I.s = V.sc[b];
   __syncthreads();
@@ -773,7 +783,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
             for (int i = tid; i < m; i += QP_T) { const double t = a.y()[i] / a.sigma()[i]; a.Axys()[i] = a.Axv()[i] + 1 * t; } /* B3 */
             __syncthreads();
             dev_active_sets(a, I);
-            if (I.s.nb_enter == 0 && I.s.nb_leave == 0) la = I.s.nb_active ? 5 : 6; /* boost_gamma */
+            if (I.s.nb_enter == 0 && I.s.nb_leave == 0) la = (I.s.nb_active && !V.kkt) ? 5 : 6; /* boost_gamma */
             else dev_update_gamma(V, a, I);
           } else dev_update_gamma(V, a, I);
           for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
@@ -795,11 +805,15 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       /* newton_set_direction, SCHUR branch (newton.c:96-113) */
       nchange = I.s.nb_enter + I.s.nb_leave;
       const double thr = qmin(st.max_rank_update_fraction * (double)(n + m), (double)st.max_rank_update);
+      if (V.kkt) { /* newton.c:32-53 */
+        action = (I.s.kkt_first || I.s.reset_newton || ((double)nchange > thr)) ? 1 : (nchange ? 2 : 0);
+        la = 8;
+      } else
       if ((I.s.reset_newton && I.s.nb_active) || ((double)nchange > thr) ||
           (V.update_rank_threshold >= 0 && I.s.nb_active && nchange > V.update_rank_threshold)) action = 1;
       else if (I.s.nb_active) action = nchange ? 2 : 0;
       else action = 3;
-      la = action;
+      if (!V.kkt) la = action;
     }
     } /* !dual_init */
     QP_OPAQUE(a.b);
@@ -816,6 +830,8 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
         __syncthreads();
         continue;
       }
+    } else if (la == 8) {
+      kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, action);
     } else if (la == 2 || la == 4) {
       const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
       dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg);
@@ -825,19 +841,22 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     if (la == 4) {
       dev_update_sigma_post(a, I, n_sig);
       if (tid == 0) { I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
-    } else if (la >= 5) dev_boost_gamma_apply(V, a, I, gersh_ub);
+    } else if (la == 5 || la == 6) dev_boost_gamma_apply(V, a, I, gersh_ub);
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
-      for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
-      __syncthreads();
-      dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg);
+      if (!V.kkt) {
+        for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
+        __syncthreads();
+        dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg);
+      }
       const long long t2 = QP_CLOCK();
       for (int i = tid; i < m; i += QP_T) a.active_old()[i] = a.active()[i];
       if (tid == 0) {
         I.s.reset_newton = 0;
+        I.s.kkt_first = 0;
         if (action == 1) { I.s.n_refactor++; I.s.ticks_factor += t1 - t0; }
         if (action == 3) { I.s.n_factor_Q++; I.s.ticks_factor += t1 - t0; }
-        if (action == 2) { I.s.n_rank1 += nchange; I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
+        if (action == 2) { if (!V.kkt) I.s.n_rank1 += nchange; I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
         I.s.n_solve++; I.s.ticks_solve += t2 - t1;
         I.s.last_fact = action;
       }

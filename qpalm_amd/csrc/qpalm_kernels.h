@@ -55,7 +55,7 @@ __global__ __launch_bounds__(QP_T) void k_setup(qpg_view V, int nscale, int mode
         for (int j = threadIdx.x; j < a.n; j += QP_T) { const double dj = a.D()[j] * a.dphi_prev()[j]; a.D()[j] = dj; a.Dinv()[j] = 1.0 / dj; }
         for (int i = threadIdx.x; i < a.m; i += QP_T) { const double ei = a.E()[i] * a.ls_delta()[i]; a.E()[i] = ei; a.Einv()[i] = 1.0 / ei; }
         __syncthreads();
-        if (threadIdx.x == 0) { I.s.sc_c *= c_temp; I.s.sc_cinv = 1 / I.s.sc_c; }
+        if (threadIdx.x == 0) { I.s.sc_c *= c_temp; I.s.sc_cinv = 1 / I.s.sc_c; I.s.kkt_first = 1; /* qpalm.c:774 */ }
         __syncthreads();
       }
     }
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
   const qpg_settings &st = *V.settings;
   const QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x, slot = b;
-  double *L = V.L + (size_t)slot * V.ld * n, *Dg = V.Dg + (size_t)slot * n, *Wst = V.Wst + (size_t)slot * V.wst_stride;
+  double *L = V.L + (size_t)slot * V.ld * V.nfac, *Dg = V.Dg + (size_t)slot * V.nfac, *Wst = V.Wst + (size_t)slot * V.wst_stride;
   if (tid == 0) I.s = V.sc[b];
   __syncthreads();
   switch (op) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_ldlsolve_all(qpg_view V, 
   for (int b = blockIdx.x; b < V.B && b < V.nslots; b += gridDim.x) {
     const QpArrays a = qp_arrays(V, b);
     const int n = a.n;
-    double *L = V.L + (size_t)b * V.ld * n, *Dg = V.Dg + (size_t)b * n;
+    double *L = V.L + (size_t)b * V.ld * V.nfac, *Dg = V.Dg + (size_t)b * V.nfac;
     for (int r = 0; r < reps; r++) {
       for (int j = threadIdx.x; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
       __syncthreads();

@@ -1,0 +1,174 @@
+/*
+ * qpalm_kkt.h -- the KKT path of newton_set_direction (src/newton.c:22-95) on the dense-panel engine:
+ *   qpalm_form_kkt / qpalm_reform_kkt + ladel_factorize*_with_diag      src/solver_interface.c:119-200, newton.c:32-45
+ *   kkt_update_entering_constraints (ladel_row_add)                     src/solver_interface.c:202-218
+ *   kkt_update_leaving_constraints  (ladel_row_del)                     src/solver_interface.c:220-236
+ *   kkt_solve + iterative refinement                                    src/solver_interface.c:238-247, newton.c:55-90
+ *
+ * K = [[Q + I/gamma, A_a'], [A_a, -Sigma_a^{-1}]] of size n + m, inactive constraints = unit diagonal rows, natural
+ * order, held as ONE dense column-major panel per resident workgroup like the Schur factor (LADEL keeps it sparse
+ * with an AMD ordering; the quasi-definite system and therefore d are the same).  A row addition / deletion is the
+ * bordering step of Davis & Hager (2005): a forward solve on the leading block, a mat-vec with the rows below, and ONE
+ * rank-1 sweep over the trailing block (dense_updown with a prestaged vector); the factor is never rebuilt for it.
+ * Included by qpalm_iter.h (needs QpArrays / IterShared).
+ */
+#ifndef QPALM_KKT_H
+#define QPALM_KKT_H
+
+/* dense lower triangle of K into the slot (qpalm_form_kkt / qpalm_reform_kkt) */
+QPD void kkt_form(const qpg_view &V, const QpArrays &a, int b, double *L, double gamma, int prox) {
+  const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x;
+  int *state = V.kkt_state + (size_t)b * m;
+  __syncthreads();
+  for (int j = 0; j < np; j++) /* zero the lower triangle, column by column (coalesced) */
+    for (int i = j + tid; i < np; i += QP_T) L[(size_t)j * ld + i] = 0.0;
+  __syncthreads();
+  for (int j = tid; j < n; j += QP_T) {
+    for (int k = a.Qp()[j]; k < a.Qp()[j + 1]; k++) { const int i = a.Qi()[k]; if (i >= j) L[(size_t)j * ld + i] += a.Qx()[k]; }
+    if (prox) L[(size_t)j * ld + j] += 1.0 / gamma;
+  }
+  for (int k = tid; k < m; k += QP_T) {
+    const int p = n + k, e0 = a.Atp()[k], e1 = a.Atp()[k + 1];
+    if (a.active()[k]) {
+      state[k] = 1;
+      for (int e = e0; e < e1; e++) L[(size_t)a.Ati()[e] * ld + p] = a.Atx()[e];
+      L[(size_t)p * ld + p] = (e1 > e0) ? -a.sigma_inv()[k] : 1.0;
+    } else { state[k] = 0; L[(size_t)p * ld + p] = 1.0; }
+  }
+  __syncthreads();
+}
+
+/* r = b - K sol with b = [-dphi; 0] (newton.c:58-62,81-84); returns max |K sol| and max |r| */
+QPD void kkt_residual(const qpg_view &V, const QpArrays &a, int b, IterShared &I, double gamma, int prox, double &norm_Ksol, double &norm_r) {
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  const double *sol = V.kkt_sol + (size_t)b * (n + m);
+  double *r = V.kkt_rhs + (size_t)b * (n + m), *lam = V.kkt_tmp + (size_t)b * (n + m);
+  const int *state = V.kkt_state + (size_t)b * m;
+  __syncthreads();
+  for (int k = tid; k < m; k += QP_T) lam[k] = (state[k] == 1) ? sol[n + k] : 0.0; /* columns truncated by nz[] do not couple */
+  __syncthreads();
+  const double ginv = 1.0 / gamma;
+  spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), sol, [&](int j, double s) { r[j] = prox ? (1 * s + ginv * sol[j]) : s; });
+  __syncthreads();
+  spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), lam, [&](int j, double s) { r[j] = r[j] + s; });
+  spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), sol, [&](int k, double s) {
+    const double xk = sol[n + k];
+    const int st = state[k];
+    const bool empty = a.Atp()[k + 1] == a.Atp()[k];
+    r[n + k] = (st == 1) ? (s + (empty ? 1.0 : -a.sigma_inv()[k]) * xk) : ((st == 2) ? -a.sigma_inv()[k] * xk : xk);
+  });
+  __syncthreads();
+  double vm[2] = {0.0, 0.0}, vs[1] = {0.0};
+  for (int j = tid; j < n + m; j += QP_T) {
+    double v = r[j] * -1;
+    vm[0] = qmax(vm[0], qabs(v));
+    if (j < n) v = 1 * v + (-1) * a.dphi()[j];
+    r[j] = v;
+    vm[1] = qmax(vm[1], qabs(v));
+  }
+  block_reduce<2, 0>(I.S, vm, vs);
+  norm_Ksol = vm[0]; norm_r = vm[1];
+}
+
+/* The whole KKT branch for one Newton step.  action: 1 (re)form + factorise, 2 row additions / deletions, 0 keep. */
+template <int RPT>
+QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *Wst, IterShared *Ip, char *lds, int action_) {
+  const qpg_view &V = *Vp;
+  IterShared &I = *Ip;
+  const int b = QP_UNIFORM(b_), action = QP_UNIFORM(action_);
+  const QpArrays a = qp_arrays(V, b);
+  const qpg_settings &st = *V.settings;
+  const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x, prox = (int)st.proximal;
+  const double gamma = I.s.gamma;
+  double *sol = V.kkt_sol + (size_t)b * np, *rhs = V.kkt_rhs + (size_t)b * np, *z = V.kkt_tmp + (size_t)b * np;
+  int *state = V.kkt_state + (size_t)b * m;
+  constexpr int K = (RPT <= 2 ? 16 : 8);
+  if (action == 1) {
+    kkt_form(V, a, b, L, gamma, prox);
+    dense_factor<RPT>(L, Dg, np, ld, lds, I.s.ticks_dbg);
+  } else if (action == 2) {
+    const int ne = I.s.nb_enter, nl = I.s.nb_leave;
+    for (int e = 0; e < ne + nl; e++) {
+      const bool add = e < ne;
+      const int k = QP_UNIFORM(add ? a.enter()[e] : a.leave()[e - ne]), p = n + k;
+      __syncthreads();
+      int up; /* sign of the trailing rank-1 term: L33 D33 L33' + (up ? + : -) w w' */
+      if (add) { /* ladel_row_add(LD, sym, n+k, kkt, n+k, -sigma_inv[k]) */
+        for (int j = tid; j < np; j += QP_T) z[j] = 0.0;
+        __syncthreads();
+        for (int q = a.Atp()[k] + tid; q < a.Atp()[k + 1]; q += QP_T) z[a.Ati()[q]] = a.Atx()[q];
+        __syncthreads();
+        dense_solve(L, Dg, p, ld, z, lds, V.lds_bytes, nullptr, 1); /* L11 z = k12 */
+        double vm[1] = {0.0}, vs[1] = {0.0};
+        for (int j = tid; j < p; j += QP_T) {
+          const double l = z[j] / Dg[j];
+          vs[0] += l * z[j];
+          L[(size_t)j * ld + p] = l; /* row p of L */
+        }
+        block_reduce<0, 1>(I.S, vm, vs);
+        const double d22 = -a.sigma_inv()[k] - vs[0];
+        const double sq = QP_SQRT(qabs(d22));
+        for (int i = tid; i < np; i += QP_T) { /* l32 = -(L31 z) / d22; its scaled copy is the rank-1 vector */
+          double wv = 0.0;
+          if (i > p) {
+            double acc = 0.0;
+            for (int j = 0; j < p; j++) acc = QP_FMA(L[(size_t)j * ld + i], z[j], acc);
+            const double l = -acc / d22;
+            L[(size_t)p * ld + i] = l;
+            wv = sq * l;
+          }
+          Wst[i] = wv;
+        }
+        if (tid == 0) { Dg[p] = d22; state[k] = 1; }
+        up = QP_UNIFORM((int)(d22 < 0)); /* - l32 d22 l32' */
+      } else { /* ladel_row_del(LD, sym, n+k) */
+        const double d22 = Dg[p];
+        __syncthreads();
+        const double sq = QP_SQRT(qabs(d22));
+        for (int i = tid; i < np; i += QP_T) {
+          double wv = 0.0;
+          if (i > p) { wv = sq * L[(size_t)p * ld + i]; L[(size_t)p * ld + i] = 0.0; }
+          Wst[i] = wv;
+        }
+        for (int j = tid; j < p; j += QP_T) L[(size_t)j * ld + p] = 0.0;
+        if (tid == 0) { Dg[p] = 1.0; state[k] = 2; }
+        up = QP_UNIFORM((int)(d22 > 0)); /* + l32 d22 l32' */
+      }
+      __syncthreads();
+      /* trailing block: one rank-1 sweep over the columns after p */
+      if (p + 1 < np)
+        dense_updown<RPT, K>(nullptr, nullptr, nullptr, np, ld, L, Dg, Wst, nullptr, up ? 1 : 0, nullptr, up ? 0 : 1, &I.S, lds, I.s.ticks_dbg, p + 1);
+    }
+    if (tid == 0) I.s.n_rank1 += ne + nl;
+  }
+  /* kkt_solve (solver_interface.c:238-247) */
+  __syncthreads();
+  for (int j = tid; j < np; j += QP_T) sol[j] = (j < n) ? a.dphi()[j] * -1 : 0.0;
+  __syncthreads();
+  dense_solve(L, Dg, np, ld, sol, lds, V.lds_bytes, I.s.ticks_dbg);
+  for (int j = tid; j < n; j += QP_T) a.d()[j] = sol[j];
+  /* iterative refinement (newton.c:57-90; constants.h:101-103) */
+  double nK, res;
+  kkt_residual(V, a, b, I, gamma, prox, nK, res);
+  double vm[1] = {0.0}, vs[1] = {0.0};
+  for (int j = tid; j < n; j += QP_T) vm[0] = qmax(vm[0], qabs(a.dphi()[j]));
+  block_reduce<1, 0>(I.S, vm, vs);
+  const double ref_norm = qmax(nK, vm[0]);
+  int kref = 0;
+  while (kref < 3 && QP_UNIFORM((int)(res > qmax(1e-10 * ref_norm, 1e-12)))) {
+    kref++;
+    __syncthreads();
+    for (int j = tid; j < np; j += QP_T) z[j] = rhs[j]; /* the correction solve works in place on a copy */
+    __syncthreads();
+    dense_solve(L, Dg, np, ld, z, lds, V.lds_bytes, I.s.ticks_dbg);
+    for (int j = tid; j < np; j += QP_T) {
+      const double dz = z[j];
+      if (j < n) a.d()[j] = dz + 1 * a.d()[j];
+      sol[j] = 1 * dz + 1 * sol[j];
+    }
+    kkt_residual(V, a, b, I, gamma, prox, nK, res);
+  }
+  __syncthreads();
+}
+
+#endif

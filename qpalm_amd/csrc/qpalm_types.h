@@ -54,7 +54,7 @@ typedef struct {
   int32_t status, done, initialized, gamma_maxed, reset_newton, in_solve;
   int32_t nb_active, nb_enter, nb_leave, nb_sigma_changed;
   int32_t last_kind, last_fact, slot, has_scaling;
-  int32_t dual_pending, pad_i0; /* dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
+  int32_t dual_pending, kkt_first; /* kkt_first: solver->first_factorization (types.h:176), KKT path; dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
   /* work counters (device side statistics for the roofline accounting in bench.py) */
   int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_spmv;
   int64_t ticks_total, ticks_factor, ticks_update, ticks_solve, ticks_linesearch, ticks_resid;
@@ -64,7 +64,9 @@ typedef struct {
 
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
-  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, pad1, pad2;
+  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride;
+  int32_t kkt, nfac; /* kkt != 0: FACTORIZE_KKT, the factor slots hold the (n+m) x (n+m) KKT panel; nfac = rows of a factor slot
+                        (n, or n + m in KKT mode); ld = its leading dimension */
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.
    * Q: lower CSC.  Qf: both triangles (row == column compressed), with permutation into Q. */
   int32_t *Ap, *Ai, *Atp, *Ati, *Atperm, *Ainv, *Qp, *Qi, *Qfp, *Qfi, *Qfperm; /* Ainv: position in A' of every entry of A */
@@ -88,6 +90,8 @@ typedef struct {
                   allocated only when enable_dual_termination is set, else NULL */
   double *DgQ; /* [nslots][n] */
   double *dual_rhs; /* [B][n] Aty + q (the reference uses neg_dphi for it, iteration.c:276) */
+  double *kkt_sol, *kkt_rhs, *kkt_tmp; /* [B][n+m] sol_kkt / rhs_kkt of the KKT path (qpalm.c:241-242) + scratch; NULL in Schur mode */
+  int32_t *kkt_state; /* [B][m] 0 unit diagonal, 1 row present, 2 deleted by row_del (solver_interface.c:151-156,226-235) */
   double *Wst; /* [nslots][wst_stride]: QPG_KMAX*n staging for rank-update vectors + a dummy row area */
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
   qpg_scalars *sc; /* [B] */

@@ -147,7 +147,7 @@ QPALMWorkspace *qpalm_setup(const QPALMData *data, const QPALMSettings *settings
   VM(delta_y); VN(Atdelta_y); VN(delta_x); VN(Qdelta_x); VM(Adelta_x);
 #undef VN
 #undef VM
-  work->solver->factorization_method = FACTORIZE_SCHUR; /* like the CHOLMOD build, solver_interface.c:72-74 */
+  qpalm_set_factorization_method(work, NULL);
   if (settings->scaling) {
     work->scaling = (QPALMScaling *)zalloc(1, sizeof(QPALMScaling));
     work->scaling->D = (c_float *)zalloc(n, sizeof(c_float)); work->scaling->Dinv = (c_float *)zalloc(n, sizeof(c_float));
@@ -323,7 +323,14 @@ void mat_inf_norm_rows(solver_sparse *M, c_float *E) { /* solver_interface.c:294
   for (size_t j = 0; j < M->nrow; j++) E[j] = 0.;
   for (size_t j = 0; j < M->ncol; j++) for (c_int k = Mp[j]; k < Mp[j + 1]; k++) { c_float a = Mx[k] < 0 ? -Mx[k] : Mx[k]; if (a > E[Mi[k]]) E[Mi[k]] = a; }
 }
-void qpalm_set_factorization_method(QPALMWorkspace *work, solver_common *c) { (void)c; work->solver->factorization_method = FACTORIZE_SCHUR; }
+/* solver_interface.c:20-75.  FACTORIZE_KKT and FACTORIZE_SCHUR are honoured.  FACTORIZE_KKT_OR_SCHUR: the reference compares
+ * nnz(KKT) with an estimate of nnz(Q + A'A) for SPARSE factors; this backend keeps the factor as one dense panel per QP,
+ * for which the n x n Schur panel is never larger than the (n+m) x (n+m) KKT panel, so the automatic choice is SCHUR
+ * (as in the reference's CHOLMOD build, :72-74).  The backend batch is created with the same rule (qpg_batch_create). */
+void qpalm_set_factorization_method(QPALMWorkspace *work, solver_common *c) {
+  (void)c;
+  work->solver->factorization_method = (work->settings->factorization_method == FACTORIZE_KKT) ? FACTORIZE_KKT : FACTORIZE_SCHUR;
+}
 
 static void push_solver_state(QPALMWorkspace *work) { /* what the boundary functions read from the workspace */
   const size_t n = work->data->n, m = work->data->m;

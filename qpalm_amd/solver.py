@@ -201,6 +201,12 @@ class QpalmBatch:
         self._check(self.L.qpg_batch_get_factor(self.h, int(b), fptr(Lm), fptr(D), self.n))
         return Lm.T.copy(), D  # column-major buffer -> [i, j]
 
+    def factor_rows(self, rows, b=0):
+        """(L, D) of a factor slot with `rows` rows: rows = n (Schur) or n + m (KKT mode)"""
+        Lm, D = np.zeros((rows, rows)), np.zeros(rows)
+        self._check(self.L.qpg_batch_get_factor(self.h, int(b), fptr(Lm), fptr(D), int(rows)))
+        return Lm.T.copy(), D
+
     # -- solver_interface.h surface ---------------------------------------------------------------
     def mat_vec(self, which, x, b=0):
         x = f64(x)

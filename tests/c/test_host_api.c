@@ -74,6 +74,13 @@ static void suite_basic_qp(void) {
   work = qpalm_setup(data, &s); qpalm_solve(work); CHECK(work->info->status_val == QPALM_MAX_ITER_REACHED); qpalm_cleanup(work);
   basic_defaults(&s); s.sigma_max = 1e3; work = qpalm_setup(data, &s); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
   basic_defaults(&s); s.time_limit = 0.01 * 1e-3; work = qpalm_setup(data, &s); qpalm_solve(work); CHECK(work->info->status_val == QPALM_TIME_LIMIT_REACHED); qpalm_cleanup(work);
+  /* the reference runs this suite in every factorization mode under LADEL (test_basic_qp.c:410-427): FACTORIZE_KKT here */
+  basic_defaults(&s); s.factorization_method = FACTORIZE_KKT; work = qpalm_setup(data, &s); CHECK(work != QPALM_NULL);
+  CHECK(work->solver->factorization_method == FACTORIZE_KKT); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
+  basic_defaults(&s); s.factorization_method = FACTORIZE_KKT; s.proximal = FALSE; s.scaling = 0;
+  work = qpalm_setup(data, &s); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
+  basic_defaults(&s); s.factorization_method = FACTORIZE_SCHUR; work = qpalm_setup(data, &s);
+  CHECK(work->solver->factorization_method == FACTORIZE_SCHUR); qpalm_solve(work); check_basic_solution(work); qpalm_cleanup(work);
   /* test_basic_qp_dual_objective (test_basic_qp.c:334-349) */
   basic_defaults(&s); s.enable_dual_termination = TRUE; work = qpalm_setup(data, &s); CHECK(work != QPALM_NULL); qpalm_solve(work);
   check_basic_solution(work); CHECK_NEAR(work->info->objective, work->info->dual_objective, 1e-5); qpalm_cleanup(work);
