@@ -129,7 +129,8 @@ void qpg_ctx_destroy(qpg_ctx *ctx);
 int  qpg_ctx_set_option(qpg_ctx *ctx, const char *name, qpg_int value); /* "lds_bytes", "max_slots",
                                                                            "update_rank_threshold" */
 
-/* A batch = B QPs with the same (n, m).  nnzA_max / nnzQ_max bound the entries of any member. */
+/* A batch = B QPs of dimensions up to (n, m) (equal for all members with qpg_batch_set_problem, smaller ones through
+ * qpg_batch_set_problem_sized).  nnzA_max / nnzQ_max bound the entries of any member. */
 int  qpg_batch_create(qpg_ctx *ctx, qpg_int B, qpg_int n, qpg_int m, qpg_int nnzA_max, qpg_int nnzQ_max,
                       const QPGSettings *settings, qpg_batch **out);
 /* CSC, 64-bit indices as in cholmod_sparse; Q symmetric, only entries with row >= col are read
@@ -137,6 +138,12 @@ int  qpg_batch_create(qpg_ctx *ctx, qpg_int B, qpg_int n, qpg_int m, qpg_int nnz
 int  qpg_batch_set_problem(qpg_batch *bt, qpg_int idx, const qpg_int *Qp, const qpg_int *Qi, const qpg_float *Qx,
                            const qpg_int *Ap, const qpg_int *Ai, const qpg_float *Ax, const qpg_float *q,
                            qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
+/* A member smaller than the batch (n <= batch n, m <= batch m): size-bucketed batches, e.g. the Maros-Meszaros QPS set
+ * streamed through interfaces/qps (BASELINE.json config 4).  The member keeps its own dimensions on the device; results
+ * come back in the batch's [B][n] / [B][m] arrays, entries beyond the member's n / m are zero. */
+int  qpg_batch_set_problem_sized(qpg_batch *bt, qpg_int idx, qpg_int n, qpg_int m, const qpg_int *Qp, const qpg_int *Qi,
+                                 const qpg_float *Qx, const qpg_int *Ap, const qpg_int *Ai, const qpg_float *Ax,
+                                 const qpg_float *q, qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
 int  qpg_batch_setup(qpg_batch *bt);                               /* upload + Ruiz scaling on device */
 int  qpg_batch_warm_start(qpg_batch *bt, const qpg_float *x, const qpg_float *y); /* [B][n], [B][m] or NULL */
 int  qpg_batch_solve(qpg_batch *bt);                               /* run every QP to termination */

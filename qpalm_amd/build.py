@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libqpalm_gfx950.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libqpalm_gfx950_emu.so")
-_SRCS = ["../host/qpalm_host.c", "qpalm_gfx950.hip", "qpalm_kernels.h", "qpalm_device.h", "qpalm_dense.h", "qpalm_iter.h", "qpalm_types.h",
+_SRCS = ["../host/qpalm_host.c", "../host/qpalm_qps.c", "qpalm_kkt.h", "qpalm_gfx950.hip", "qpalm_kernels.h", "qpalm_device.h", "qpalm_dense.h", "qpalm_iter.h", "qpalm_types.h",
          "qpalm_capi.inc"]
 
 
@@ -47,9 +47,22 @@ def build_host():
     """The C host library (reference API names, include/qpalm_host.h) on top of the HIP library."""
     out = os.path.join(HERE, "lib", "libqpalm.so")
     libdir = os.path.dirname(LIB)
-    subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-o", out,
-                           os.path.join(HERE, "host", "qpalm_host.c"), "-L" + libdir, "-lqpalm_gfx950",
-                           "-Wl,-rpath,$ORIGIN", "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-fPIC", "-shared", "-Wall", "-o", out,
+                           os.path.join(HERE, "host", "qpalm_host.c"), os.path.join(HERE, "host", "qpalm_qps.c"),
+                           "-L" + libdir, "-lqpalm_gfx950", "-Wl,-rpath,$ORIGIN", "-lm"])
+    # the reference's CLI (interfaces/qps/src/qpalm_qps.c main): qpalm_qps problem.qps [settings.txt]
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQPALM_QPS_MAIN", "-Wall", "-o", os.path.join(HERE, "lib", "qpalm_qps"),
+                           os.path.join(HERE, "host", "qpalm_qps.c"), "-L" + libdir, "-lqpalm", "-lqpalm_gfx950", "-Wl,-rpath,$ORIGIN", "-lm"])
+    return out
+
+
+def build_host_emu():
+    """TEST-ONLY: the same host C layer on top of the emulated kernels (tests/emu)."""
+    out = os.path.join(EMU_DIR, "libqpalm_host_emu.so")
+    build_emu()
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-fPIC", "-shared", "-Wall", "-o", out,
+                           os.path.join(HERE, "host", "qpalm_host.c"), os.path.join(HERE, "host", "qpalm_qps.c"),
+                           "-L" + EMU_DIR, "-lqpalm_gfx950_emu", "-Wl,-rpath," + EMU_DIR, "-lm"])
     return out
 
 

@@ -78,6 +78,7 @@ def load(path=None):
     L.qpg_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, c_int]
     L.qpg_batch_create.argtypes = [C.c_void_p, c_int, c_int, c_int, c_int, c_int, C.POINTER(Settings), C.POINTER(C.c_void_p)]
     L.qpg_batch_set_problem.argtypes = [C.c_void_p, c_int, pi, pi, pf, pi, pi, pf, pf, c_float, pf, pf]
+    L.qpg_batch_set_problem_sized.argtypes = [C.c_void_p, c_int, c_int, c_int, pi, pi, pf, pi, pi, pf, pf, c_float, pf, pf]
     for f in ("qpg_batch_setup", "qpg_batch_solve", "qpg_batch_sync", "qpg_batch_begin_solve"):
         getattr(L, f).argtypes = [C.c_void_p]
     L.qpg_batch_warm_start.argtypes = [C.c_void_p, pf, pf]
@@ -128,7 +129,7 @@ SYMBOLS = [
     "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints", "qpg_ldldowndate_leaving_constraints",
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
     "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
-    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs",
+    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_batch_set_problem_sized",
 ]
 
 

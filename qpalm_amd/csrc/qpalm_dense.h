@@ -78,15 +78,15 @@ QPD double qp_rcp(double x) {
  * GERSH = true: no Q, full columns, returns max_j (C_jj + sum_{i!=j} |C_ij|)  (nonconvex.c:185-210).
  * (GERSH is a run-time flag so that the kernel holds ONE copy of this loop nest.)
  * ------------------------------------------------------------------------------------------- */
-QPN double form_schur(const qpg_view &V, int b, double *Lslot, const bool GERSH, bool with_AtSA, bool proximal, double gamma,
+QPN double form_schur(const qpg_view &V, int b, const int n, double *Lslot, const bool GERSH, bool with_AtSA, bool proximal, double gamma,
                       QpShared &S, char *lds) {
-  const int n = V.n, ld = V.ld;
+  const int ld = V.ld; /* n = this QP's dimension; the per-QP strides below are the batch's V.n / V.m */
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int *Ap = V.Ap + (size_t)b * (n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
+  const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
   const int *Ainv = V.Ainv + (size_t)b * V.nnzA;
-  const int *Qp = V.Qp + (size_t)b * (n + 1), *Qi = V.Qi + (size_t)b * V.nnzQ;
+  const int *Qp = V.Qp + (size_t)b * (V.n + 1), *Qi = V.Qi + (size_t)b * V.nnzQ;
   const double *Qx = V.Qx + (size_t)b * V.nnzQ;
   const int *active = V.active + (size_t)b * V.m;
   int ncb = V.lds_bytes / (8 * n);

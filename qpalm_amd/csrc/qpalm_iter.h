@@ -89,7 +89,8 @@ struct QpArrays { /* per-QP views; base pointers are recomputed on use to keep S
 
 QPD QpArrays qp_arrays(const qpg_view &V, int b) {
   QpArrays a;
-  a.V = &V; a.b = b; a.n = V.n; a.m = V.m;
+  a.V = &V; a.b = b;
+  a.n = V.nq ? QP_UNIFORM(V.nq[b]) : V.n; a.m = V.mq ? QP_UNIFORM(V.mq[b]) : V.m; /* strides stay V.n / V.m */
   return a;
 }
 
@@ -239,12 +240,12 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
  * factorisation plumbing
  * =========================================================================================== */
 template <int RPT>
-QPN void dev_factor(const qpg_view &V, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, V.n, V.ld, lds, tdbg); }
+QPN void dev_factor(const qpg_view &V, int n, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, n, V.ld, lds, tdbg); }
 template <int RPT>
-QPN void dev_updown(const qpg_view &V, int b, double *L, double *Dg, double *Wst, const int *up, int n_up,
+QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, double *Wst, const int *up, int n_up,
                     const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
   dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA,
-                                         V.n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg);
+                                         n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg);
 }
 
 /* =============================================================================================
@@ -821,9 +822,9 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     double gersh_ub = 0.0;
     if (la == 1 || la == 3 || la == 5 || la == 7) {
       double *Lt = (la == 7) ? LQ : L, *Dt = (la == 7) ? DgQ : Dg;
-      gersh_ub = form_schur(V, b, Lt, la == 5, la == 1 || la == 5, (la == 1 || la == 3) && (prox != 0), gam, I.S, lds);
+      gersh_ub = form_schur(V, b, n, Lt, la == 5, la == 1 || la == 5, (la == 1 || la == 3) && (prox != 0), gam, I.S, lds);
       if (tid == 0) I.s.ticks_dbg[3] += QP_CLOCK() - t0;
-      if (la != 5) dev_factor<RPT>(V, Lt, Dt, lds, I.s.ticks_dbg);
+      if (la != 5) dev_factor<RPT>(V, n, Lt, Dt, lds, I.s.ticks_dbg);
       if (dual_init) { /* qpalm.c:459-468: LD_Q is ready, the dual objective of the starting point (scalar branch) */
         const double dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
         if (tid == 0) { I.s.dual_objective = dobj; I.s.dual_pending = 0; }
@@ -834,7 +835,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, action);
     } else if (la == 2 || la == 4) {
       const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
-      dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg);
+      dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg);
     }
     const long long t1 = QP_CLOCK();
     QP_OPAQUE(a.b);

@@ -203,24 +203,24 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
     case QP_OP_MATVEC_Q: spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
     case QP_OP_MATTVEC_A: spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
     case QP_OP_LDLCHOL:
-      form_schur(V, b, L, false, false, st.proximal != 0, I.s.gamma, I.S, lds);
-      dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
+      form_schur(V, b, n, L, false, false, st.proximal != 0, I.s.gamma, I.S, lds);
+      dev_factor<RPT>(V, n, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_FACTOR_LOADED: /* the host wrote a symmetric matrix (lower triangle) into the slot */
       if (st.proximal) for (int j = tid; j < n; j += QP_T) L[(size_t)j * V.ld + j] += 1.0 / I.s.gamma;
       __syncthreads();
-      dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
+      dev_factor<RPT>(V, n, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_LDLCHOL_QATSA:
-      form_schur(V, b, L, false, true, st.proximal != 0, I.s.gamma, I.S, lds);
-      dev_factor<RPT>(V, L, Dg, lds, I.s.ticks_dbg);
+      form_schur(V, b, n, L, false, true, st.proximal != 0, I.s.gamma, I.S, lds);
+      dev_factor<RPT>(V, n, L, Dg, lds, I.s.ticks_dbg);
       break;
-    case QP_OP_UPDATE_ENTER: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), 0, I.S, lds, I.s.ticks_dbg); break;
-    case QP_OP_DOWNDATE_LEAVE: dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), 0, a.leave(), I.s.nb_leave, I.S, lds, I.s.ticks_dbg); break;
+    case QP_OP_UPDATE_ENTER: dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), 0, I.S, lds, I.s.ticks_dbg); break;
+    case QP_OP_DOWNDATE_LEAVE: dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), 0, a.leave(), I.s.nb_leave, I.S, lds, I.s.ticks_dbg); break;
     case QP_OP_UPDATE_SIGMA: { /* solver_interface.c:443-503; At_scale and the changed list (enter) were set by the caller */
       const int nchg = I.s.nb_sigma_changed;
       dev_ldlupdate_sigma_scale(a, nchg);
-      dev_updown<RPT>(V, b, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds, I.s.ticks_dbg);
+      dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), nchg, a.leave(), 0, I.S, lds, I.s.ticks_dbg);
       dev_update_sigma_post(a, I, nchg);
       break;
     }

@@ -18,7 +18,7 @@
 /* dense lower triangle of K into the slot (qpalm_form_kkt / qpalm_reform_kkt) */
 QPD void kkt_form(const qpg_view &V, const QpArrays &a, int b, double *L, double gamma, int prox) {
   const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x;
-  int *state = V.kkt_state + (size_t)b * m;
+  int *state = V.kkt_state + (size_t)b * V.m;
   __syncthreads();
   for (int j = 0; j < np; j++) /* zero the lower triangle, column by column (coalesced) */
     for (int i = j + tid; i < np; i += QP_T) L[(size_t)j * ld + i] = 0.0;
@@ -41,9 +41,10 @@ QPD void kkt_form(const qpg_view &V, const QpArrays &a, int b, double *L, double
 /* r = b - K sol with b = [-dphi; 0] (newton.c:58-62,81-84); returns max |K sol| and max |r| */
 QPD void kkt_residual(const qpg_view &V, const QpArrays &a, int b, IterShared &I, double gamma, int prox, double &norm_Ksol, double &norm_r) {
   const int n = a.n, m = a.m, tid = threadIdx.x;
-  const double *sol = V.kkt_sol + (size_t)b * (n + m);
-  double *r = V.kkt_rhs + (size_t)b * (n + m), *lam = V.kkt_tmp + (size_t)b * (n + m);
-  const int *state = V.kkt_state + (size_t)b * m;
+  const size_t sk = (size_t)V.n + V.m; /* batch strides */
+  const double *sol = V.kkt_sol + (size_t)b * sk;
+  double *r = V.kkt_rhs + (size_t)b * sk, *lam = V.kkt_tmp + (size_t)b * sk;
+  const int *state = V.kkt_state + (size_t)b * V.m;
   __syncthreads();
   for (int k = tid; k < m; k += QP_T) lam[k] = (state[k] == 1) ? sol[n + k] : 0.0; /* columns truncated by nz[] do not couple */
   __syncthreads();
@@ -80,8 +81,9 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
   const qpg_settings &st = *V.settings;
   const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x, prox = (int)st.proximal;
   const double gamma = I.s.gamma;
-  double *sol = V.kkt_sol + (size_t)b * np, *rhs = V.kkt_rhs + (size_t)b * np, *z = V.kkt_tmp + (size_t)b * np;
-  int *state = V.kkt_state + (size_t)b * m;
+  const size_t sk = (size_t)V.n + V.m; /* batch strides */
+  double *sol = V.kkt_sol + (size_t)b * sk, *rhs = V.kkt_rhs + (size_t)b * sk, *z = V.kkt_tmp + (size_t)b * sk;
+  int *state = V.kkt_state + (size_t)b * V.m;
   constexpr int K = (RPT <= 2 ? 16 : 8);
   if (action == 1) {
     kkt_form(V, a, b, L, gamma, prox);

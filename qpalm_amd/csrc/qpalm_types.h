@@ -91,6 +91,7 @@ typedef struct {
   double *DgQ; /* [nslots][n] */
   double *dual_rhs; /* [B][n] Aty + q (the reference uses neg_dphi for it, iteration.c:276) */
   double *kkt_sol, *kkt_rhs, *kkt_tmp; /* [B][n+m] sol_kkt / rhs_kkt of the KKT path (qpalm.c:241-242) + scratch; NULL in Schur mode */
+  int32_t *nq, *mq;   /* [B] per-QP dimensions (<= n, m: members of a mixed-size batch are padded to the batch strides); NULL = uniform */
   int32_t *kkt_state; /* [B][m] 0 unit diagonal, 1 row present, 2 deleted by row_del (solver_interface.c:151-156,226-235) */
   double *Wst; /* [nslots][wst_stride]: QPG_KMAX*n staging for rank-update vectors + a dummy row area */
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */

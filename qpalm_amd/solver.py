@@ -66,8 +66,8 @@ class QpalmBatch:
         """problems: sequence of objects with .args() -> (n, m, Qp, Qi, Qx, Ap, Ai, Ax, q, bmin, bmax) and .c"""
         self.ctx, self.L = ctx, ctx.L
         self.B = len(problems)
-        p0 = problems[0]
-        self.n, self.m = int(p0.n), int(p0.m)
+        self.n, self.m = max(int(p.n) for p in problems), max(int(p.m) for p in problems)
+        self.dims = [(int(p.n), int(p.m)) for p in problems]   # members may be smaller than the batch (mixed sizes)
         nnzA = max(int(p.Ap[-1]) for p in problems)
         nnzQ = max(int(p.Qp[-1]) for p in problems)
         self.settings = settings if settings is not None else ctx.default_settings()
@@ -75,12 +75,10 @@ class QpalmBatch:
         self._check(self.L.qpg_batch_create(ctx.h, self.B, self.n, self.m, nnzA, nnzQ, C.byref(self.settings), C.byref(h)))
         self.h = h
         for b, p in enumerate(problems):
-            if p.n != self.n or p.m != self.m:
-                raise ValueError("all QPs of a batch must share (n, m)")
             Qp, Qi, Qx, Ap, Ai, Ax = i64(p.Qp), i64(p.Qi), f64(p.Qx), i64(p.Ap), i64(p.Ai), f64(p.Ax)
             q, bmin, bmax = f64(p.q), f64(p.bmin), f64(p.bmax)
-            self._check(self.L.qpg_batch_set_problem(self.h, b, iptr(Qp), iptr(Qi), fptr(Qx), iptr(Ap), iptr(Ai), fptr(Ax),
-                                                     fptr(q), float(getattr(p, "c", 0.0)), fptr(bmin), fptr(bmax)))
+            self._check(self.L.qpg_batch_set_problem_sized(self.h, b, int(p.n), int(p.m), iptr(Qp), iptr(Qi), fptr(Qx), iptr(Ap), iptr(Ai),
+                                                           fptr(Ax), fptr(q), float(getattr(p, "c", 0.0)), fptr(bmin), fptr(bmax)))
         self._check(self.L.qpg_batch_setup(self.h))
 
     def _check(self, rc):
@@ -153,6 +151,12 @@ class QpalmBatch:
 
     def begin_solve(self):
         self._check(self.L.qpg_batch_begin_solve(self.h))
+
+    def solution_of(self, k):
+        """(x, y) of member k without the padding of a mixed-size batch"""
+        x, y = self.solution()
+        n, m = self.dims[k]
+        return x[k, :n], y[k, :m]
 
     def statuses(self):
         return np.array([int(i.status_val) for i in self.infos()])

@@ -30,8 +30,8 @@ def _emit_header(golden):
 
 def _build_and_run(libdir, backend_lib, host_out):
     src = os.path.join(ROOT, "qpalm_amd", "host", "qpalm_host.c")
-    subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-o", host_out, src,
-                           "-L" + libdir, "-l" + backend_lib, "-Wl,-rpath," + libdir, "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-fPIC", "-shared", "-Wall", "-o", host_out, src,
+                           os.path.join(ROOT, "qpalm_amd", "host", "qpalm_qps.c"), "-L" + libdir, "-l" + backend_lib, "-Wl,-rpath," + libdir, "-lm"])
     exe = os.path.join(CDIR, "test_host_api_" + backend_lib)
     subprocess.check_call(["gcc", "-O1", "-std=c99", "-Wall", "-o", exe, os.path.join(CDIR, "test_host_api.c"), host_out,
                            "-Wl,-rpath," + os.path.dirname(host_out), "-Wl,-rpath," + libdir, "-L" + libdir, "-l" + backend_lib, "-lm"])
