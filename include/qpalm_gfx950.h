@@ -113,6 +113,8 @@ typedef struct {
                            line search: 13 SpMVs, 14 breakpoints + compaction, 15 sort (the scan is the rest) */
   qpg_int sweep_entries;         /* entries of L the rank-update sweeps touched (each read and written once): sum of nnz(L[:, J0:]) */
   qpg_int factor_reread_entries; /* entries of L re-read by the panel updates of the factorisations (beyond the compulsory write) */
+  qpg_float lobpcg_lambda;       /* nonconvex QPs: the eigenvalue bound of lobpcg (nonconvex.c:29-168); gamma_init = gamma_max = 1/|lambda| */
+  qpg_int lobpcg_iter, nonconvex; /* LOBPCG iterations; settings->nonconvex of THIS QP after set_settings_nonconvex (:171-183) */
 } QPGStats;
 
 typedef struct qpg_ctx qpg_ctx;

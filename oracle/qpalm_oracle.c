@@ -19,6 +19,7 @@
 #include "qpalm_oracle.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -79,7 +80,8 @@ struct oq_workspace {
                               2 deleted by row_del (diagonal -1/sigma kept for the refinement mat-vec, :233-235) */
   oq_float *rhs_kkt, *sol_kkt, *kkt_tmp;
   oq_sparse At;            /* transpose of the (scaled) A: row k of A = column k (solver->At, qpalm.c:250) */
-  oq_int n_row_add, n_row_del, n_refine;
+  oq_int n_row_add, n_row_del, n_refine, n_lobpcg_iter;
+  oq_float lobpcg_lambda;
   oq_float *Hbuf; /* scratch n*n for forming Q + A'SA */
   oq_float *wbuf; /* scratch n for rank-1 vectors */
   /* settings / solution / info */
@@ -322,6 +324,149 @@ static void factor_sparse_lower(oq_workspace *w, const oq_sparse *M, oq_factor *
   F->valid = 1;
 }
 
+
+/* =========================================================================================
+ * nonconvex.c restated: lobpcg (:29-168), set_settings_nonconvex (:171-183).  gershgorin_max (:185-210) is above.
+ * Third-party pieces absent from the reference tree, restated from their published definitions:
+ *   - rand(): the reference seeds the start vector from the UNSEEDED C library generator (B9), i.e. glibc's default
+ *     state (seed 1) in a fresh process.  glibc's TYPE_3 generator is restated (r_i = r_{i-3} + r_{i-31} on 32 bits,
+ *     seeded by the Lehmer sequence 16807 r mod 2^31-1, first 310 outputs discarded, result >> 1; RAND_MAX = 2^31-1);
+ *     tests check it against the C library of the build host.
+ *   - LAPACKE_dsyev on the 2 x 2 and LAPACKE_dsygv (itype 1) on the 3 x 3 compressed pencil: eigenvalues ascending,
+ *     eigenvectors C-normalised.  Restated with a cyclic Jacobi iteration on G^{-1} B G^{-T} (C = G G', Cholesky),
+ *     which is what dsygv does up to its QR iteration; the sign of an eigenvector is LAPACK's choice and does not
+ *     influence lambda (x -> -x flips w and p consistently).
+ * ======================================================================================= */
+typedef struct { int32_t r[34]; int f, b; } oq_glibc_rand;
+static void oq_srand(oq_glibc_rand *g, unsigned int seed) {
+  int32_t word = seed ? (int32_t)seed : 1;
+  int32_t tab[344];
+  tab[0] = word;
+  for (int i = 1; i < 31; i++) {
+    long hi = tab[i - 1] / 127773, lo = tab[i - 1] % 127773;
+    long v = 16807 * lo - 2836 * hi;
+    if (v < 0) v += 2147483647;
+    tab[i] = (int32_t)v;
+  }
+  for (int i = 31; i < 34; i++) tab[i] = tab[i - 31];
+  for (int i = 34; i < 344; i++) tab[i] = (int32_t)((uint32_t)tab[i - 31] + (uint32_t)tab[i - 3]);
+  for (int i = 0; i < 34; i++) g->r[i] = tab[310 + i];
+  g->f = 0; (void)g->b;
+}
+static int oq_rand(oq_glibc_rand *g) { /* o_k = o_{k-31} + o_{k-3}; the 34 newest values are kept in a ring */
+  const int k = g->f;                                      /* slot of o_{k-34} -> becomes o_k */
+  const uint32_t v = (uint32_t)g->r[(k + 3) % 34] + (uint32_t)g->r[(k + 31) % 34];
+  g->r[k] = (int32_t)v;
+  g->f = (k + 1) % 34;
+  return (int)(v >> 1);
+}
+int oq_rand_sequence(unsigned int seed, int count, int *out) { /* for the test against the C library */
+  oq_glibc_rand g; oq_srand(&g, seed);
+  for (int i = 0; i < count; i++) out[i] = oq_rand(&g);
+  return 0;
+}
+
+static oq_float vec_norm_two(const oq_float *a, size_t n) { return sqrt(oq_vec_prod(a, a, n)); } /* lin_alg.c:165-167 */
+
+/* smallest eigenpair of the symmetric-definite pencil (B, C) of order dim (2 or 3), C = I for dim 2 */
+static oq_float small_eig(int dim, oq_float B[3][3], oq_float Cm[3][3], oq_float y[3]) {
+  oq_float G[3][3] = {{0}}, M[3][3], T[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int j = 0; j < dim; j++) { /* C = G G' */
+    oq_float s = Cm[j][j];
+    for (int k = 0; k < j; k++) s -= G[j][k] * G[j][k];
+    G[j][j] = sqrt(s);
+    for (int i = j + 1; i < dim; i++) { oq_float t = Cm[i][j]; for (int k = 0; k < j; k++) t -= G[i][k] * G[j][k]; G[i][j] = t / G[j][j]; }
+  }
+  for (int c = 0; c < dim; c++) /* T = G^{-1} B (forward substitution on every column) */
+    for (int i = 0; i < dim; i++) { oq_float t = B[i][c]; for (int k = 0; k < i; k++) t -= G[i][k] * T[k][c]; T[i][c] = t / G[i][i]; }
+  for (int r = 0; r < dim; r++) /* M = T G^{-T}: rows of T solved against G */
+    for (int i = 0; i < dim; i++) { oq_float t = T[r][i]; for (int k = 0; k < i; k++) t -= G[i][k] * M[r][k]; M[r][i] = t / G[i][i]; }
+  for (int i = 0; i < dim; i++) for (int j = 0; j < i; j++) { const oq_float a = 0.5 * (M[i][j] + M[j][i]); M[i][j] = a; M[j][i] = a; }
+  for (int sweep = 0; sweep < 30; sweep++) { /* cyclic Jacobi */
+    oq_float off = 0;
+    for (int i = 0; i < dim; i++) for (int j = 0; j < i; j++) off += M[i][j] * M[i][j];
+    if (off == 0.0) break;
+    for (int p = 0; p < dim; p++)
+      for (int q = p + 1; q < dim; q++) {
+        if (M[p][q] == 0.0) continue;
+        const oq_float theta = (M[q][q] - M[p][p]) / (2.0 * M[p][q]);
+        const oq_float t = (theta >= 0 ? 1.0 : -1.0) / (OQ_ABS(theta) + sqrt(theta * theta + 1.0));
+        const oq_float cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < dim; k++) { const oq_float a = M[k][p], b = M[k][q]; M[k][p] = cs * a - sn * b; M[k][q] = sn * a + cs * b; }
+        for (int k = 0; k < dim; k++) { const oq_float a = M[p][k], b = M[q][k]; M[p][k] = cs * a - sn * b; M[q][k] = sn * a + cs * b; }
+        for (int k = 0; k < dim; k++) { const oq_float a = V[k][p], b = V[k][q]; V[k][p] = cs * a - sn * b; V[k][q] = sn * a + cs * b; }
+      }
+  }
+  int kmin = 0;
+  for (int k = 1; k < dim; k++) if (M[k][k] < M[kmin][kmin]) kmin = k;
+  for (int i = dim - 1; i >= 0; i--) { /* y = G^{-T} v */
+    oq_float t = V[i][kmin];
+    for (int k = i + 1; k < dim; k++) t -= G[k][i] * y[k];
+    y[i] = t / G[i][i];
+  }
+  return M[kmin][kmin];
+}
+
+static oq_float lobpcg(oq_workspace *w) { /* nonconvex.c:29-168 with x == NULL */
+  const size_t n = (size_t)w->n;
+  const oq_sparse *A = &w->Q;
+  oq_float *x = w->d, *Ax = w->Qd, *wv = w->neg_dphi, *Aw = w->Atyh, *p = w->temp_n, *Ap = w->xx0;
+  oq_glibc_rand g; oq_srand(&g, 1);
+  for (size_t i = 0; i < n; i++) x[i] = (oq_float)oq_rand(&g) / 2147483647;
+  oq_vec_self_mult_scalar(x, 1.0 / vec_norm_two(x, n), n);
+  oq_mat_vec(A, x, Ax);
+  oq_float lambda = oq_vec_prod(x, Ax, n);
+  oq_vec_add_scaled(Ax, x, wv, -lambda, n);
+  oq_vec_add_scaled(wv, x, wv, -oq_vec_prod(x, wv, n), n);
+  oq_vec_self_mult_scalar(wv, 1.0 / vec_norm_two(wv, n), n);
+  oq_mat_vec(A, wv, Aw);
+  oq_float xAw = oq_vec_prod(Aw, x, n), wAw = oq_vec_prod(Aw, wv, n);
+  oq_float B[3][3] = {{lambda, xAw, 0}, {xAw, wAw, 0}, {0, 0, 0}}, Cm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, y[3] = {0, 0, 0};
+  lambda = small_eig(2, B, Cm, y);
+  for (size_t i = 0; i < n; i++) { p[i] = wv[i] * y[1]; Ap[i] = Aw[i] * y[1]; } /* vec_mult_scalar */
+  oq_vec_add_scaled(p, x, x, y[0], n);
+  oq_vec_add_scaled(Ap, Ax, Ax, y[0], n);
+  w->n_lobpcg_iter = 0;
+  for (size_t it = 0; it < 1000; it++) {
+    oq_vec_add_scaled(Ax, x, wv, -lambda, n);
+    if (oq_vec_norm_inf(wv, n) < 1e-5) { /* LOBPCG_TOL */
+      const oq_float norm_w = vec_norm_two(wv, n);
+      lambda -= sqrt(2) * norm_w + 1e-6;
+      if (n <= 3) lambda -= 1e-6;
+      break;
+    }
+    w->n_lobpcg_iter++;
+    oq_vec_add_scaled(wv, x, wv, -oq_vec_prod(x, wv, n), n);
+    oq_vec_self_mult_scalar(wv, 1.0 / vec_norm_two(wv, n), n);
+    oq_mat_vec(A, wv, Aw);
+    xAw = oq_vec_prod(Ax, wv, n);
+    wAw = oq_vec_prod(wv, Aw, n);
+    const oq_float p_norm_inv = 1.0 / vec_norm_two(p, n);
+    oq_vec_self_mult_scalar(p, p_norm_inv, n);
+    oq_vec_self_mult_scalar(Ap, p_norm_inv, n);
+    const oq_float xAp = oq_vec_prod(Ax, p, n), wAp = oq_vec_prod(Aw, p, n), pAp = oq_vec_prod(Ap, p, n);
+    const oq_float xp = oq_vec_prod(x, p, n), wp = oq_vec_prod(wv, p, n);
+    oq_float B3[3][3] = {{lambda, xAw, xAp}, {xAw, wAw, wAp}, {xAp, wAp, pAp}}, C3[3][3] = {{1, 0, xp}, {0, 1, wp}, {xp, wp, 1.0}};
+    lambda = small_eig(3, B3, C3, y);
+    oq_vec_mult_add_scaled(p, wv, y[2], y[1], n);
+    oq_vec_mult_add_scaled(Ap, Aw, y[2], y[1], n);
+    oq_vec_mult_add_scaled(x, p, y[0], 1, n);
+    oq_vec_mult_add_scaled(Ax, Ap, y[0], 1, n);
+  }
+  return lambda;
+}
+
+static void set_settings_nonconvex(oq_workspace *w) { /* nonconvex.c:171-183 */
+  const oq_float lambda = lobpcg(w);
+  w->lobpcg_lambda = lambda;
+  if (lambda < 0) {
+    w->settings.proximal = 1;
+    w->settings.gamma_init = 1 / OQ_ABS(lambda);
+    w->settings.gamma_max = w->settings.gamma_init;
+    w->gamma_maxed = 1;
+  } else w->settings.nonconvex = 0;
+}
+
 /* =========================================================================================
  * timers / status (src/util.c:61-105, :283-303)
  * ======================================================================================= */
@@ -473,7 +618,7 @@ oq_workspace *oq_setup(oq_int n_, oq_int m_, const oq_int *Qp, const oq_int *Qi,
     w->kkt_state = izalloc(m);
     w->rhs_kkt = zalloc(n + m); w->sol_kkt = zalloc(n + m); w->kkt_tmp = zalloc(n + m);
   }
-  /* nonconvex (set_settings_nonconvex, nonconvex.c:171-183) is a next-tier row */
+  if (w->settings.nonconvex) set_settings_nonconvex(w); /* qpalm.c:293-296 */
   w->sol_x = zalloc(n); w->sol_y = zalloc(m);
   update_status(&w->info, OQ_UNSOLVED);
   w->info.solve_time = 0.0; w->info.run_time = 0.0;
@@ -1401,6 +1546,8 @@ oq_float oq_get_scalar(const oq_workspace *w, const char *name) {
   if (!strcmp(name, "eps_abs_in")) return w->eps_abs_in;
   if (!strcmp(name, "eps_rel_in")) return w->eps_rel_in;
   if (!strcmp(name, "sqrt_sigma_max")) return w->sqrt_sigma_max;
+  if (!strcmp(name, "lobpcg_lambda")) return w->lobpcg_lambda;
+  if (!strcmp(name, "gamma_init")) return w->settings.gamma_init;
   return NAN;
 }
 void oq_set_scalar(oq_workspace *w, const char *name, oq_float v) {
@@ -1423,6 +1570,8 @@ oq_int oq_get_counter(const oq_workspace *w, const char *name) {
   if (!strcmp(name, "n_row_add")) return w->n_row_add;
   if (!strcmp(name, "n_row_del")) return w->n_row_del;
   if (!strcmp(name, "n_refine")) return w->n_refine;
+  if (!strcmp(name, "n_lobpcg_iter")) return w->n_lobpcg_iter;
+  if (!strcmp(name, "nonconvex")) return w->settings.nonconvex;
   if (!strcmp(name, "kkt_mode")) return w->kkt_mode;
   if (!strcmp(name, "nb_active")) return w->nb_active;
   if (!strcmp(name, "nb_enter")) return w->nb_enter;

@@ -170,6 +170,7 @@ void     oq_scale_data(oq_workspace *w);
 
 /* ---- dense LDL^T kernels on raw arrays (column-major, unit lower L, ld = leading dim) ---- */
 /* H (lower triangle, column-major, ld) is overwritten by L (strict lower) ; D gets the pivots. */
+int  oq_rand_sequence(unsigned int seed, int count, int *out); /* restated glibc rand() (nonconvex.c:42, B9) */
 void oq_dense_ldl_factor(oq_int n, oq_float *H, oq_int ld, oq_float *D);
 void oq_dense_ldl_solve(oq_int n, const oq_float *L, oq_int ld, const oq_float *D, oq_float *b);
 /* LDL' <- LDL' + sign * w w'  (w is destroyed), Davis & Hager method C1 as used by CHOLMOD */

@@ -48,7 +48,8 @@ class Stats(C.Structure):
                                      "n_boost_gamma", "nb_active", "nb_enter", "nb_leave", "last_kind", "last_fact")] + \
                [(k, c_float) for k in ("gamma", "tau", "eta", "beta", "eps_pri", "eps_dua", "eps_dua_in", "sc_c",
                                        "ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")] + \
-               [("ms_dbg", c_float * 16), ("sweep_entries", c_int), ("factor_reread_entries", c_int)]
+               [("ms_dbg", c_float * 16), ("sweep_entries", c_int), ("factor_reread_entries", c_int),
+                ("lobpcg_lambda", c_float), ("lobpcg_iter", c_int), ("nonconvex", c_int)]
 
 
 class QpgError(RuntimeError):

@@ -16,6 +16,11 @@
 #define QP_KIND_FORCED 2
 #define QP_KIND_TERMINATED 3
 
+/* settings that set_settings_nonconvex (nonconvex.c:171-183) overrides per workspace: per-QP values for nonconvex QPs */
+QPD int qp_prox(const qpg_settings &st, const qpg_scalars &s) { return (st.proximal != 0 || s.nc_flag != 0) ? 1 : 0; }
+QPD double qp_gamma_init(const qpg_settings &st, const qpg_scalars &s) { return s.nc_flag ? s.nc_gamma : st.gamma_init; }
+QPD double qp_gamma_max(const qpg_settings &st, const qpg_scalars &s) { return s.nc_flag ? s.nc_gamma : st.gamma_max; }
+
 struct IterShared {
   QpShared S;
   qpg_scalars s;
@@ -166,7 +171,7 @@ QPN double dev_objective(const qpg_view &V, const QpArrays &a, IterShared &I, do
   double vm[1] = {0.0}, vs[1] = {0.0};
   const double g = I.s.gamma;
   for (int j = threadIdx.x; j < a.n; j += QP_T) {
-    if (st.proximal) vs[0] += (0.5 * (a.Qxv()[j] - 1 / g * a.x()[j]) + a.q()[j]) * a.x()[j];
+    if (qp_prox(st, I.s)) vs[0] += (0.5 * (a.Qxv()[j] - 1 / g * a.x()[j]) + a.q()[j]) * a.x()[j];
     else vs[0] += (0.5 * a.Qxv()[j] + a.q()[j]) * a.x()[j];
   }
   block_reduce<0, 1>(I.S, vm, vs);
@@ -181,7 +186,7 @@ QPN double dev_objective(const qpg_view &V, const QpArrays &a, IterShared &I, do
 QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, int has_y, IterShared &I) {
   const qpg_settings &st = *V.settings;
   const int n = a.n, m = a.m, tid = threadIdx.x;
-  if (tid == 0) I.s.gamma = st.gamma_init;
+  if (tid == 0) I.s.gamma = qp_gamma_init(st, I.s);
   __syncthreads();
   if (has_x) {
     for (int j = tid; j < n; j += QP_T) {
@@ -190,8 +195,8 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
       a.x()[j] = xv; a.x0()[j] = xv; a.x_prev()[j] = xv;
     }
     __syncthreads();
-    const double ginv = 1 / st.gamma_init;
-    const int prox = (int)st.proximal;
+    const double ginv = 1 / qp_gamma_init(st, I.s);
+    const int prox = qp_prox(st, I.s);
     spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), a.x(), [&](int r, double s) {
       a.Qd()[r] = s;
       a.Qxv()[r] = prox ? (s + ginv * a.x()[r]) : s;
@@ -318,11 +323,11 @@ QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
     /* FACTORIZE_KKT (iteration.c:135-144, solver_interface.c:463-481): every branch that changes anything ends in
      * reset_newton = TRUE; the reference's rank-1 correction is applied at row pinv[row] (a variable's row) and is
      * overwritten by the refactorisation that reset_newton forces, so it is not restated */
-    if (I.s.kkt_first || (st.proximal && I.s.gamma < st.gamma_max) || nchg > 0) { if (tid == 0) I.s.reset_newton = 1; }
+    if (I.s.kkt_first || (qp_prox(st, I.s) && I.s.gamma < qp_gamma_max(st, I.s)) || nchg > 0) { if (tid == 0) I.s.reset_newton = 1; }
     __syncthreads();
     return 0;
   }
-  if ((st.proximal && I.s.gamma < st.gamma_max) || ((double)nchg > thr)) {
+  if ((qp_prox(st, I.s) && I.s.gamma < qp_gamma_max(st, I.s)) || ((double)nchg > thr)) {
     if (tid == 0) I.s.reset_newton = 1;
   } else if (nchg == 0) {
   } else {
@@ -348,9 +353,9 @@ QPN void dev_update_sigma_post(const QpArrays &a, IterShared &I, int nchg) {
 QPN void dev_update_gamma(const qpg_view &V, const QpArrays &a, IterShared &I) {
   const qpg_settings &st = *V.settings;
   __syncthreads();
-  if (I.s.gamma < st.gamma_max) {
+  if (I.s.gamma < qp_gamma_max(st, I.s)) {
     const double prev = I.s.gamma;
-    const double g = qmin(prev * st.gamma_upd, st.gamma_max);
+    const double g = qmin(prev * st.gamma_upd, qp_gamma_max(st, I.s));
     const double sc = 1 / g - 1 / prev;
     for (int j = threadIdx.x; j < a.n; j += QP_T) a.Qxv()[j] = a.Qxv()[j] + sc * a.x()[j];
     __syncthreads();
@@ -383,7 +388,7 @@ QPN void dev_boost_gamma_apply(const qpg_view &V, const QpArrays &a, IterShared 
   const double prev = I.s.gamma;
   double g;
   if (I.s.nb_active) {
-    g = V.kkt ? 1e10 : qmax(st.gamma_max, 1e14 / ub); /* iteration.c:173-176 under FACTORIZE_KKT */
+    g = V.kkt ? 1e10 : qmax(qp_gamma_max(st, I.s), 1e14 / ub); /* iteration.c:173-176 under FACTORIZE_KKT */
     if (threadIdx.x == 0) I.s.gamma_maxed = 1;
   } else g = 1e12;
   __syncthreads();
@@ -424,7 +429,7 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
   const qpg_settings &st = *V.settings;
   const int n = a.n, m = a.m, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double ginv = 1 / I.s.gamma;
-  const int prox = (int)st.proximal;
+  const int prox = qp_prox(st, I.s);
   __syncthreads();
   long long tl0 = QP_CLOCK();
   spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), a.d(), [&](int r, double s) { a.Qd()[r] = prox ? (s + ginv * a.d()[r]) : s; });
@@ -590,7 +595,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
   if (!I.s.in_solve) { /* qpalm.c:409-482 */
     if (tid == 0) {
       I.s.eps_abs_in = st.eps_abs_in; I.s.eps_rel_in = st.eps_rel_in;
-      I.s.reset_newton = 1; I.s.gamma = st.gamma_init; I.s.gamma_maxed = (0 || st.nonconvex);
+      I.s.reset_newton = 1; I.s.gamma = qp_gamma_init(st, I.s); I.s.gamma_maxed = (0 || I.s.nc_flag);
     }
     for (int i = tid; i < m; i += QP_T) a.active_old()[i] = 0;
     __syncthreads();
@@ -608,7 +613,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     }
     __syncthreads();
   }
-  const int scal = I.s.has_scaling, prox = (int)st.proximal;
+  const int scal = I.s.has_scaling, prox = qp_prox(st, I.s);
   int executed = 0;
   while (true) {
     /* At most ONE linear-algebra operation per pass, so form_schur / factor / update each have a
@@ -720,6 +725,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       s.dua_res_norm = vm[4]; s.dua2_res_norm = vm[5];
       if (scal) { s.dua_res_norm *= s.sc_cinv; s.dua2_res_norm *= s.sc_cinv; }
       s.eps_pri = st.eps_abs + st.eps_rel * vm[1];
+      s.norm_Ax_z = vm[1];
       double mx = vm[6];
       if (scal) mx *= s.sc_cinv;
       s.eps_dua = st.eps_abs + st.eps_rel * mx;
@@ -779,6 +785,18 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
           I.s.eps_rel_in = qmax(st.eps_rel, st.rho * I.s.eps_rel_in);
         }
         __syncthreads();
+        if (I.s.nc_flag) { /* qpalm.c:586-611: the proximal point and the tolerances move only when the subproblem is feasible enough */
+          const double eps_k = I.s.eps_k_abs + I.s.eps_k_rel * I.s.norm_Ax_z; /* B1: the Einv.*Ax half only when scaled */
+          if (I.s.pri_res_norm < eps_k) {
+            for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
+            __syncthreads();
+            if (tid == 0) {
+              I.s.eps_k_abs = qmax(st.eps_abs, st.rho * I.s.eps_k_abs);
+              I.s.eps_k_rel = qmax(st.eps_rel, st.rho * I.s.eps_k_rel);
+            }
+          }
+          __syncthreads();
+        } else
         if (prox) { /* qpalm.c:612-630 (convex) */
           if (!I.s.gamma_maxed && I.s.iter_out > 0 && I.s.nb_enter == 0 && I.s.nb_leave == 0 && I.s.pri_res_norm < I.s.eps_pri) {
             for (int i = tid; i < m; i += QP_T) { const double t = a.y()[i] / a.sigma()[i]; a.Axys()[i] = a.Axv()[i] + 1 * t; } /* B3 */
@@ -791,7 +809,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
         }
       } else if (prox) { /* qpalm.c:647-660 */
         dev_update_gamma(V, a, I);
-        if (!st.nonconvex) for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
+        if (!I.s.nc_flag) for (int j = tid; j < n; j += QP_T) a.x0()[j] = a.x()[j];
       }
       for (int i = tid; i < m; i += QP_T) a.pri_res_in()[i] = a.pri_res()[i];
       __syncthreads();

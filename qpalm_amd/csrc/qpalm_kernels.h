@@ -65,6 +65,164 @@ __global__ __launch_bounds__(QP_T) void k_setup(qpg_view V, int nscale, int mode
   }
 }
 
+
+/* =============================================================================================
+ * set_settings_nonconvex + lobpcg (src/nonconvex.c:29-183), one workgroup per QP, at setup time (qpalm.c:293-296).
+ * LOBPCG stops on ||A x - lambda x||_inf < 1e-5, so its iteration count -- and with it gamma = 1/|lambda| and every
+ * later iterate -- depends on the last bits of its dot products.  This is a setup-time routine, so the sums are done
+ * in the REFERENCE'S ORDER: vec_prod in groups of four (lin_alg.c:72-86; the groups in parallel, their total by one
+ * thread), the symmetric mat-vec row by row in cholmod_sdmult's accumulation order, element-wise updates without fma.
+ * The 2 x 2 / 3 x 3 (generalised) eigenproblems of the compressed pencil replace LAPACKE_dsyev / dsygv by a Cholesky
+ * reduction + cyclic Jacobi in registers of thread 0.  The start vector is the C library's unseeded rand() sequence
+ * (B9), restated on the host (glibc TYPE_3, seed 1) and uploaded into d.
+ * =========================================================================================== */
+struct LobpcgShared { double g[QP_T]; double y[3]; double lambda; double scal; };
+
+QPD double lob_dot(LobpcgShared &S, const double *u, const double *v, int n) { /* vec_prod, lin_alg.c:72-86 */
+  const int ng = n / 4, tid = threadIdx.x;
+  __syncthreads();
+  for (int k = tid; k < ng; k += QP_T) { const int i = 4 * k; S.g[k] = (u[i] * v[i] + u[i + 1] * v[i + 1] + u[i + 2] * v[i + 2] + u[i + 3] * v[i + 3]); }
+  __syncthreads();
+  if (tid == 0) {
+    double prod = 0.0;
+    for (int k = 0; k < ng; k++) prod += S.g[k];
+    for (int i = 4 * ng; i < n; i++) prod += u[i] * v[i];
+    S.scal = prod;
+  }
+  __syncthreads();
+  return S.scal;
+}
+QPD double lob_norm2(LobpcgShared &S, const double *u, int n) { return QP_SQRT(lob_dot(S, u, u, n)); }
+QPD void lob_matvec(const QpArrays &a, const double *x, double *y) { /* cholmod_sdmult on the lower triangle (stype -1) */
+  __syncthreads();
+  for (int r = threadIdx.x; r < a.n; r += QP_T) {
+    double up = 0.0, lo = 0.0; /* Y[r] collects the columns before r; the column's own accumulator starts at zero */
+    for (int k = a.Qfp()[r]; k < a.Qfp()[r + 1]; k++) {
+      const int c = a.Qfi()[k];
+      const double t = a.Qfx()[k] * x[c];
+      if (c < r) up += t; else lo += t;
+    }
+    y[r] = up + lo;
+  }
+  __syncthreads();
+}
+/* smallest eigenpair of the symmetric-definite pencil (B, C) of order dim (2 or 3): C = G G', Jacobi on G^{-1} B G^{-T} */
+QPD double lob_small_eig(int dim, double B[3][3], double Cm[3][3], double y[3]) {
+  double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, M[3][3], T[3][3], Vv[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int j = 0; j < dim; j++) {
+    double s = Cm[j][j];
+    for (int k = 0; k < j; k++) s -= G[j][k] * G[j][k];
+    G[j][j] = QP_SQRT(s);
+    for (int i = j + 1; i < dim; i++) { double t = Cm[i][j]; for (int k = 0; k < j; k++) t -= G[i][k] * G[j][k]; G[i][j] = t / G[j][j]; }
+  }
+  for (int c = 0; c < dim; c++)
+    for (int i = 0; i < dim; i++) { double t = B[i][c]; for (int k = 0; k < i; k++) t -= G[i][k] * T[k][c]; T[i][c] = t / G[i][i]; }
+  for (int r = 0; r < dim; r++)
+    for (int i = 0; i < dim; i++) { double t = T[r][i]; for (int k = 0; k < i; k++) t -= G[i][k] * M[r][k]; M[r][i] = t / G[i][i]; }
+  for (int i = 0; i < dim; i++) for (int j = 0; j < i; j++) { const double av = 0.5 * (M[i][j] + M[j][i]); M[i][j] = av; M[j][i] = av; }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0;
+    for (int i = 0; i < dim; i++) for (int j = 0; j < i; j++) off += M[i][j] * M[i][j];
+    if (off == 0.0) break;
+    for (int p = 0; p < dim; p++)
+      for (int q = p + 1; q < dim; q++) {
+        if (M[p][q] == 0.0) continue;
+        const double theta = (M[q][q] - M[p][p]) / (2.0 * M[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (qabs(theta) + QP_SQRT(theta * theta + 1.0));
+        const double cs = 1.0 / QP_SQRT(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < dim; k++) { const double av = M[k][p], bv = M[k][q]; M[k][p] = cs * av - sn * bv; M[k][q] = sn * av + cs * bv; }
+        for (int k = 0; k < dim; k++) { const double av = M[p][k], bv = M[q][k]; M[p][k] = cs * av - sn * bv; M[q][k] = sn * av + cs * bv; }
+        for (int k = 0; k < dim; k++) { const double av = Vv[k][p], bv = Vv[k][q]; Vv[k][p] = cs * av - sn * bv; Vv[k][q] = sn * av + cs * bv; }
+      }
+  }
+  int kmin = 0;
+  for (int k = 1; k < dim; k++) if (M[k][k] < M[kmin][kmin]) kmin = k;
+  for (int i = dim - 1; i >= 0; i--) {
+    double t = Vv[i][kmin];
+    for (int k = i + 1; k < dim; k++) t -= G[k][i] * y[k];
+    y[i] = t / G[i][i];
+  }
+  return M[kmin][kmin];
+}
+
+__global__ __launch_bounds__(QP_T) void k_lobpcg(qpg_view V) {
+  __shared__ LobpcgShared S;
+  __shared__ IterShared I;
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < V.B; b += gridDim.x) {
+    const QpArrays a = qp_arrays(V, b);
+    const int n = a.n;
+    double *x = a.d(), *Ax = a.Qd(), *w = a.dphi(), *Aw = a.Atyh(), *p = a.temp_n(), *Ap = a.delta_x();
+    __syncthreads();
+    if (tid == 0) I.s = V.sc[b];
+    __syncthreads();
+    /* x <- rand()/RAND_MAX normalised (the host wrote the raw sequence into d) */
+    { const double nx = lob_norm2(S, x, n); const double sc = 1.0 / nx; for (int i = tid; i < n; i += QP_T) x[i] *= sc; }
+    lob_matvec(a, x, Ax);
+    double lambda = lob_dot(S, x, Ax, n);
+    for (int i = tid; i < n; i += QP_T) w[i] = Ax[i] + (-lambda) * x[i];
+    { const double xw = lob_dot(S, x, w, n); for (int i = tid; i < n; i += QP_T) w[i] = w[i] + (-xw) * x[i]; }
+    { const double nw = lob_norm2(S, w, n); const double sc = 1.0 / nw; for (int i = tid; i < n; i += QP_T) w[i] *= sc; }
+    lob_matvec(a, w, Aw);
+    double xAw = lob_dot(S, Aw, x, n), wAw = lob_dot(S, Aw, w, n);
+    if (tid == 0) {
+      double Bm[3][3] = {{lambda, xAw, 0}, {xAw, wAw, 0}, {0, 0, 0}}, Cm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, yv[3] = {0, 0, 0};
+      S.lambda = lob_small_eig(2, Bm, Cm, yv);
+      S.y[0] = yv[0]; S.y[1] = yv[1]; S.y[2] = yv[2];
+    }
+    __syncthreads();
+    lambda = S.lambda;
+    { const double y0 = S.y[0], y1 = S.y[1];
+      for (int i = tid; i < n; i += QP_T) { p[i] = w[i] * y1; Ap[i] = Aw[i] * y1; x[i] = p[i] + y0 * x[i]; Ax[i] = Ap[i] + y0 * Ax[i]; } }
+    int iters = 0;
+    for (int it = 0; it < 1000; it++) {
+      __syncthreads();
+      double vm[1] = {0.0}, vs[1] = {0.0};
+      for (int i = tid; i < n; i += QP_T) { const double wi = Ax[i] + (-lambda) * x[i]; w[i] = wi; vm[0] = qmax(vm[0], qabs(wi)); }
+      block_reduce<1, 0>(I.S, vm, vs);
+      if (vm[0] < 1e-5) { /* LOBPCG_TOL */
+        const double norm_w = lob_norm2(S, w, n);
+        lambda -= QP_SQRT(2.0) * norm_w + 1e-6;
+        if (n <= 3) lambda -= 1e-6;
+        break;
+      }
+      iters++;
+      { const double xw = lob_dot(S, x, w, n); for (int i = tid; i < n; i += QP_T) w[i] = w[i] + (-xw) * x[i]; }
+      { const double nw = lob_norm2(S, w, n); const double sc = 1.0 / nw; for (int i = tid; i < n; i += QP_T) w[i] *= sc; }
+      lob_matvec(a, w, Aw);
+      xAw = lob_dot(S, Ax, w, n);
+      wAw = lob_dot(S, w, Aw, n);
+      { const double pn = lob_norm2(S, p, n); const double pinv = 1.0 / pn; for (int i = tid; i < n; i += QP_T) { p[i] *= pinv; Ap[i] *= pinv; } }
+      const double xAp = lob_dot(S, Ax, p, n), wAp = lob_dot(S, Aw, p, n), pAp = lob_dot(S, Ap, p, n);
+      const double xp = lob_dot(S, x, p, n), wp = lob_dot(S, w, p, n);
+      if (tid == 0) {
+        double Bm[3][3] = {{lambda, xAw, xAp}, {xAw, wAw, wAp}, {xAp, wAp, pAp}}, Cm[3][3] = {{1, 0, xp}, {0, 1, wp}, {xp, wp, 1.0}}, yv[3];
+        S.lambda = lob_small_eig(3, Bm, Cm, yv);
+        S.y[0] = yv[0]; S.y[1] = yv[1]; S.y[2] = yv[2];
+      }
+      __syncthreads();
+      lambda = S.lambda;
+      const double y0 = S.y[0], y1 = S.y[1], y2 = S.y[2];
+      for (int i = tid; i < n; i += QP_T) {
+        const double pi = y2 * p[i] + y1 * w[i], api = y2 * Ap[i] + y1 * Aw[i];
+        p[i] = pi; Ap[i] = api;
+        x[i] = y0 * x[i] + 1 * pi; Ax[i] = y0 * Ax[i] + 1 * api;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { /* set_settings_nonconvex */
+      I.s.lobpcg_lambda = lambda; I.s.lobpcg_iter = iters;
+      if (lambda < 0) { I.s.nc_flag = 1; I.s.nc_gamma = 1 / qabs(lambda); I.s.gamma = I.s.nc_gamma; I.s.gamma_maxed = 1; }
+      else I.s.nc_flag = 0;
+      V.sc[b] = I.s;
+    }
+    __syncthreads();
+    /* the vectors used as scratch go back to what qpalm_setup leaves in them (calloc'ed zeros) */
+    for (int i = tid; i < n; i += QP_T) { x[i] = 0.0; Ax[i] = 0.0; w[i] = 0.0; Aw[i] = 0.0; p[i] = 0.0; Ap[i] = 0.0; }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(QP_T) void k_warm_start(qpg_view V, int has_x, int has_y) {
   __shared__ IterShared I;
   for (int b = blockIdx.x; b < V.B; b += gridDim.x) {
@@ -132,7 +290,7 @@ __global__ __launch_bounds__(QP_T) void k_update_q(qpg_view V) {
         const double qj = a.D()[j] * a.q()[j];
         a.q()[j] = qj;
         double Qxj = a.Qxv()[j];
-        if (st.proximal) Qxj = Qxj + mg * a.x()[j];
+        if (qp_prox(st, I.s)) Qxj = Qxj + mg * a.x()[j];
         a.Qxv()[j] = Qxj;
         const double t = qj + cinv_old * Qxj;
         vm[0] = qmax(vm[0], qabs(t));
@@ -140,11 +298,11 @@ __global__ __launch_bounds__(QP_T) void k_update_q(qpg_view V) {
       block_reduce<1, 0>(I.S, vm, vs);
       const double c = 1 / qmax(1.0, vm[0]);
       const double ratio = c / c_old;
-      const double ginit = st.gamma_init;
+      const double ginit = qp_gamma_init(st, I.s);
       for (int j = threadIdx.x; j < a.n; j += QP_T) {
         a.q()[j] *= c;
         double Qxj = a.Qxv()[j] * ratio;
-        if (st.proximal) Qxj = Qxj + (1 / ginit) * a.x()[j];
+        if (qp_prox(st, I.s)) Qxj = Qxj + (1 / ginit) * a.x()[j];
         a.Qxv()[j] = Qxj;
       }
       const int nzQ = a.Qp()[a.n], nzQf = a.Qfp()[a.n];
@@ -153,7 +311,7 @@ __global__ __launch_bounds__(QP_T) void k_update_q(qpg_view V) {
       for (int k = threadIdx.x; k < nzQf; k += QP_T) a.Qfx()[k] = a.Qx()[a.Qfperm()[k]];
       if (threadIdx.x == 0) {
         I.s.sc_c = c; I.s.sc_cinv = 1 / c;
-        if (st.proximal) I.s.gamma = ginit;
+        if (qp_prox(st, I.s)) I.s.gamma = ginit;
         V.sc[b] = I.s;
       }
     }
@@ -180,7 +338,7 @@ QPN void dev_compute_residuals(const qpg_view &V, const QpArrays &a, IterShared 
   const double mginv = -1 / I.s.gamma;
   for (int j = tid; j < n; j += QP_T) {
     double dfv = a.Qxv()[j] + 1 * a.q()[j];
-    if (st.proximal) dfv = dfv + mginv * a.x0()[j];
+    if (qp_prox(st, I.s)) dfv = dfv + mginv * a.x0()[j];
     a.df()[j] = dfv;
     a.dphi()[j] = dfv + 1 * a.Atyh()[j];
   }
@@ -203,16 +361,16 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
     case QP_OP_MATVEC_Q: spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
     case QP_OP_MATTVEC_A: spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
     case QP_OP_LDLCHOL:
-      form_schur(V, b, n, L, false, false, st.proximal != 0, I.s.gamma, I.S, lds);
+      form_schur(V, b, n, L, false, false, qp_prox(st, I.s) != 0, I.s.gamma, I.S, lds);
       dev_factor<RPT>(V, n, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_FACTOR_LOADED: /* the host wrote a symmetric matrix (lower triangle) into the slot */
-      if (st.proximal) for (int j = tid; j < n; j += QP_T) L[(size_t)j * V.ld + j] += 1.0 / I.s.gamma;
+      if (qp_prox(st, I.s)) for (int j = tid; j < n; j += QP_T) L[(size_t)j * V.ld + j] += 1.0 / I.s.gamma;
       __syncthreads();
       dev_factor<RPT>(V, n, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_LDLCHOL_QATSA:
-      form_schur(V, b, n, L, false, true, st.proximal != 0, I.s.gamma, I.S, lds);
+      form_schur(V, b, n, L, false, true, qp_prox(st, I.s) != 0, I.s.gamma, I.S, lds);
       dev_factor<RPT>(V, n, L, Dg, lds, I.s.ticks_dbg);
       break;
     case QP_OP_UPDATE_ENTER: dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), I.s.nb_enter, a.leave(), 0, I.S, lds, I.s.ticks_dbg); break;

@@ -79,7 +79,7 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
   const int b = QP_UNIFORM(b_), action = QP_UNIFORM(action_);
   const QpArrays a = qp_arrays(V, b);
   const qpg_settings &st = *V.settings;
-  const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x, prox = (int)st.proximal;
+  const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x, prox = qp_prox(st, I.s);
   const double gamma = I.s.gamma;
   const size_t sk = (size_t)V.n + V.m; /* batch strides */
   double *sol = V.kkt_sol + (size_t)b * sk, *rhs = V.kkt_rhs + (size_t)b * sk, *z = V.kkt_tmp + (size_t)b * sk;

@@ -50,6 +50,12 @@ typedef struct {
   double sqrt_sigma_max, sqrt_delta, sc_c, sc_cinv;
   double pri_res_norm, dua_res_norm, dua2_res_norm, objective, dual_objective;
   double setup_time, solve_time;
+  /* nonconvex QPs (set_settings_nonconvex, nonconvex.c:171-183, changes settings PER WORKSPACE; a batch shares one settings
+   * block, so the per-QP values live here): nc_flag = settings->nonconvex after LOBPCG (lambda < 0), nc_gamma = 1/|lambda|
+   * = this QP's gamma_init = gamma_max (proximal forced on), lobpcg_lambda / lobpcg_iter for inspection,
+   * norm_Ax_z = the norm of eps_pri (termination.c:92-100) reused by the nonconvex tolerance eps_k (qpalm.c:586-596) */
+  double nc_gamma, lobpcg_lambda, norm_Ax_z;
+  int32_t nc_flag, lobpcg_iter;
   int32_t iter, iter_out, prev_iter, no_change;
   int32_t status, done, initialized, gamma_maxed, reset_newton, in_solve;
   int32_t nb_active, nb_enter, nb_leave, nb_sigma_changed;

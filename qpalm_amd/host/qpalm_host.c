@@ -191,6 +191,17 @@ QPALMWorkspace *qpalm_setup(const QPALMData *data, const QPALMSettings *settings
     return QPALM_NULL;
   }
   pull(work);
+  if (settings->nonconvex) { /* set_settings_nonconvex ran on the device (nonconvex.c:171-183): mirror what it did to the settings */
+    QPGStats gs;
+    if (qpg_batch_get_stats(stt->bt, 0, &gs) == QPG_OK) {
+      if (gs.nonconvex) {
+        work->settings->proximal = TRUE;
+        work->settings->gamma_init = 1 / (gs.lobpcg_lambda < 0 ? -gs.lobpcg_lambda : gs.lobpcg_lambda);
+        work->settings->gamma_max = work->settings->gamma_init;
+        work->gamma_maxed = TRUE;
+      } else work->settings->nonconvex = FALSE;
+    }
+  }
   set_status(work->info, QPALM_UNSOLVED);
   return work;
 }

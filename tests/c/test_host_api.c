@@ -142,6 +142,26 @@ static void suite_update(void) {
   free_data(data);
 }
 
+/* suite_nonconvex (tests/src/test_nonconvex_qp.c:117-139): the three factorization modes */
+static void suite_nonconvex(void) {
+  QPALMData *data = make_data(&golden_nonconvex_qp);
+  const c_int methods[3] = {FACTORIZE_KKT_OR_SCHUR, FACTORIZE_KKT, FACTORIZE_SCHUR};
+  for (int k = 0; k < 3; k++) {
+    QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.nonconvex = TRUE; s.scaling = FALSE;
+    s.max_rank_update_fraction = 1.0; s.factorization_method = methods[k]; s.verbose = g_verbose;
+    QPALMWorkspace *work = qpalm_setup(data, &s);
+    CHECK(work != QPALM_NULL);
+    if (!work) continue;
+    CHECK(work->settings->proximal == TRUE && work->settings->gamma_max == work->settings->gamma_init);
+    qpalm_solve(work);
+    CHECK(work->info->status_val == QPALM_SOLVED);
+    CHECK_NEAR(work->gamma, 1.0 / 0.0021544347, 1e-1 * 1.0 / 0.0021544347); /* inverse of the lowest eigenvalue */
+    CHECK(1 / work->gamma > 0.0021544347);                                   /* the eigenvalue is under-approximated */
+    qpalm_cleanup(work);
+  }
+  free_data(data);
+}
+
 /* suite_solver (tests/src/test_solver_interface.c:106-160) */
 static void suite_solver(void) {
   QPALMData *data = make_data(&golden_solver_interface);
@@ -180,6 +200,7 @@ int main(void) {
     suite_degen_hess();
     suite_infeasible();
     suite_update();
+    suite_nonconvex();
   }
   printf("%d checks, %d failures\n", g_checks, g_fail);
   return g_fail ? 1 : 0;

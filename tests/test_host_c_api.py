@@ -15,7 +15,7 @@ def _emit_header(golden):
 
     def arr(t, name, v):
         return "static const %s %s[] = {%s};" % (t, name, ", ".join(repr(x) for x in (v if len(v) else [0])))
-    for name in ("basic_qp", "degen_hess", "prim_inf_qp", "dua_inf_qp", "update", "solver_interface"):
+    for name in ("basic_qp", "degen_hess", "prim_inf_qp", "dua_inf_qp", "update", "solver_interface", "nonconvex_qp"):
         p = golden["problems"][name]
         for k in ("Ap", "Ai", "Qp", "Qi"):
             out.append(arr("int64_t", "%s_%s" % (name, k), [int(x) for x in p[k]]))

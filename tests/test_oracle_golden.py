@@ -293,3 +293,15 @@ def test_lin_alg(golden):
     for k in range(8, 11):
         ref += u[k] * v[k]
     assert L.oq_vec_prod(fp(u), fp(v), 11) == ref
+
+
+def test_nonconvex_qp_golden(golden):
+    """tests/src/test_nonconvex_qp.c:117-126 on the oracle's restated lobpcg / set_settings_nonconvex"""
+    from qpalm_amd.problems import fixture_qp
+    e = golden["expect"]["nonconvex_qp"]
+    p = fixture_qp(golden["problems"]["nonconvex_qp"])
+    o = ob.OracleQP(*p.args(), settings=ob.default_settings(eps_abs=1e-6, eps_rel=1e-6, nonconvex=1, scaling=0, max_rank_update_fraction=1.0, verbose=0))
+    o.solve()
+    assert o.status_val == 1
+    lam = -e["lambda_min"]
+    assert abs(o.scalar("gamma") - 1.0 / lam) <= e["gamma_rel_tol"] / lam and 1 / o.scalar("gamma") > lam
