@@ -34,6 +34,20 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RESIDENT_WORKGROUPS = 512  # 2 workgroups per CU x 256 CUs (QP_WAVES_PER_SIMD = 4)
 
 
+def source_sha256():
+    """hash of the kernel + C-ABI sources: a PMC summary is only quoted for the build it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "qpalm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+DEFAULT_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "final", "k_solve_pmc_traffic.json")
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,9 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
-    ap.add_argument("--traffic-json", default=None,
-                    help="PMC summary written by tools/round_artifacts.sh for THIS build and command (stamped with the git SHA); "
-                         "without it roofline.traffic is null")
+    ap.add_argument("--traffic-json", default=DEFAULT_TRAFFIC_JSON,
+                    help="PMC summary written by tools/round_artifacts.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                         "command).  It is quoted only if its source hash equals the hash of the kernel sources in this tree and the "
+                         "workload matches; otherwise roofline.traffic is null")
     return ap.parse_args(argv)
 
 
@@ -345,10 +360,14 @@ def worker(args):
         ms_ldl = bt.ldlsolve_all(reps=4)                    # stand-alone LDL' solve kernel ("HBM GB/s on LDL")
         ldl_bytes = nsl * model0["b_solve"]
         traffic = None
-        if args.traffic_json and world == 1:
+        traffic_src = None
+        if args.traffic_json and world == 1 and args.workload == "random-1000":
             try:
                 with open(args.traffic_json) as f:
-                    traffic = float(json.load(f)["traffic_bytes_per_launch"])
+                    pj = json.load(f)
+                if pj["source_sha256"] == source_sha256() and (pj["batch"], pj["n"], pj["m"]) == (B, n, m):
+                    traffic = float(pj["traffic_bytes_per_launch"])
+                    traffic_src = os.path.relpath(args.traffic_json, ROOT)
             except Exception:
                 traffic = None
         out = {
@@ -361,7 +380,7 @@ def worker(args):
                        "update_rank_threshold": args.rank_threshold},
             "roofline": {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes,
                          "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "bytes_note": "update bytes = 16 B x entries of L[:, J0:] actually swept (device counter), not the 8d upper bound",
                          "phases": phases},

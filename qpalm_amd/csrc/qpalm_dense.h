@@ -414,6 +414,40 @@ QP_NI_FROWS void factor_panel_rows(double *L_, char *lds_, const int n_, const i
   if (jb == NB) rows(std::true_type()); else rows(std::false_type());
 }
 
+/* Step (2) of dense_factor as its own function (own register allocation): the staged 32 x 32 diagonal block (rows
+ * beyond the matrix = identity) is factorised by ONE wavefront with the whole block in registers: lane = row (both
+ * half-waves hold the same rows), register c = column c.  Per column c: the pivot and the un-normalised column entries
+ * p(c2, c) are wave-uniform values fetched with v_readlane (no LDS round trip on the chain), one division per column,
+ * then p(r, c2) <- fma(-l(r, c), p(c2, c), p(r, c2)) for c2 > c: the same fma per entry, in the same order (c
+ * ascending), as the LDS form it replaces (measured there: ~1 us per column; the mpc-160 factorisation spent 40 % here). */
+#ifndef QP_NI_FDIAG
+#define QP_NI_FDIAG QPNI
+#endif
+QP_NI_FDIAG void factor_diag_block(char *lds_) {
+  FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
+  constexpr int NB = QP_FNB;
+  const int r = (int)(threadIdx.x & (NB - 1));
+  double p[NB];
+#pragma unroll
+  for (int c = 0; c < NB; c++) p[c] = F.Ld[r][c];
+#pragma unroll
+  for (int c = 0; c < NB; c++) {
+    const double dc = qp_readlane(p[c], c);
+    const double lic = p[c] / dc;
+#pragma unroll
+    for (int c2 = c + 1; c2 < NB; c2++) {
+      const double s = qp_readlane(p[c], c2); /* p(c2, c), still un-normalised */
+      p[c2] = QP_FMA(-lic, s, p[c2]);       /* meaningful for rows r >= c2; rows above the diagonal are never read */
+    }
+    p[c] = lic;
+    if (r == c && threadIdx.x < NB) { F.dv[c] = 1.0 / dc; F.dg[c] = dc; } /* reciprocal pivot for the panel rows */
+  }
+  if (threadIdx.x < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; c++) if (r > c) F.Ld[r][c] = p[c];
+  }
+}
+
 template <int RPT>
 #ifndef QP_NI_FACTOR
 #define QP_NI_FACTOR QPNI
@@ -457,37 +491,14 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *l
     }
     __syncthreads();
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[4] += tq1 - tq0; tq0 = tq1; }
-    /* ---- (2) diagonal block: right-looking LDL' inside LDS.  The tile is staged by all threads;
-     * wavefront 0 eliminates column by column (lane & 31 = row, the two half-waves take alternate
-     * target columns), rolled loop and unconditional LDS traffic: no per-column lane masks or
-     * addresses to keep alive under the 128-VGPR cap.  Same FMAs per entry as the register version:
-     * p(r,c2) <- fma(-l(r,c), p(c2,c), p(r,c2)) for c ascending, l(r,c) = p(r,c) / p(c,c). ---------- */
+    /* ---- (2) diagonal block: staged in LDS by all threads (rows beyond the matrix = identity), factorised by
+     * wavefront 0 in registers (factor_diag_block), written back by all threads ---------------------------------- */
     for (int e = tid; e < NB * NB; e += QP_T) {
       const int c = e / NB, r = e % NB;
       F.Ld[r][c] = (r >= c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (wid == 0) {
-#pragma unroll 1
-      for (int c = 0; c < jb; c++) {
-        const int ln = QP_FRESH_LANE(lane);
-        const int r = ln & (NB - 1), h = ln >> 5;
-        const double dc = F.Ld[c][c];
-        const double prc = F.Ld[r][c];
-        const double lic = (r > c) ? prc / dc : 0.0; /* rows <= c: no-op updates below */
-#pragma unroll 4
-        for (int c2 = c + 1 + h; c2 < NB; c2 += 2) {
-          const double t = QP_FMA(-lic, F.Ld[c2][c], F.Ld[r][c2]);
-          if (r >= c2) F.Ld[r][c2] = t;
-        }
-        QP_WAVE_SYNC();
-        if (h == 0) {
-          if (r > c) F.Ld[r][c] = lic;
-          if (r == c) { F.dv[c] = 1.0 / dc; F.dg[c] = dc; } /* reciprocal pivot for the panel rows */
-        }
-        QP_WAVE_SYNC();
-      }
-    }
+    if (wid == 0) factor_diag_block(lds_);
     __syncthreads();
     for (int e = tid; e < jb * jb; e += QP_T) {
       const int c = e / jb, r = e % jb;

@@ -1,0 +1,40 @@
+"""Summarises the rocprofv3 PMC passes of tools/round_artifacts.sh for k_solve: HBM bytes per launch as
+MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half of the
+bytes of wide coalesced reads -> doubled), the SQ wait/active shares, stamped with the hash of the kernel sources."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out, repo = sys.argv[1], sys.argv[2]
+sys.path.insert(0, repo)
+from bench import source_sha256  # noqa: E402
+
+
+def per_launch(d, counter):
+    tot, n = 0.0, 0
+    for f in glob.glob(os.path.join(out, d, "**", "*counter_collection*.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_solve" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                tot += float(r["Counter_Value"]); n += 1
+    return (tot / n if n else None), n
+
+
+fe, nf = per_launch("pmc_fetch", "FETCH_SIZE")
+wr, nw = per_launch("pmc_write", "WRITE_SIZE")
+sq = {}
+for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+          "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+    v, n = per_launch("pmc_sq", c)
+    if v is not None:
+        sq[c] = v
+res = {"kernel": "k_solve<2>", "command": "python bench.py --steps 1 --warmup 0 --no-cpu (default batch 4096, n=1000, m=2000)",
+       "batch": 4096, "n": 1000, "m": 2000, "source_sha256": source_sha256(),
+       "FETCH_SIZE_KB_per_launch": fe, "WRITE_SIZE_KB_per_launch": wr, "launches_seen": [nf, nw],
+       "gfx950_correction": "FETCH_SIZE x 2 (128-byte requests tallied at 64 B), WRITE_SIZE as reported",
+       "traffic_bytes_per_launch": (2 * fe + wr) * 1024 if fe is not None and wr is not None else None, "sq": sq}
+if sq.get("SQ_WAVE_CYCLES"):
+    wc = sq["SQ_WAVE_CYCLES"]
+    res["sq_shares"] = {k: sq[k] / wc for k in sq if k != "SQ_WAVE_CYCLES"}
+print(json.dumps(res, indent=1))

@@ -1,31 +1,26 @@
 #!/bin/bash
-# Round-end evidence, run on the GPU box:  tools/round_artifacts.sh   (outputs under gpurun_out/r01/)
+# Round evidence, run on the GPU box:  bash tools/round_artifacts.sh [round]   (outputs under gpurun_out/<round>/final/)
+# Copies to profiles/<round>/ are made by hand from the merged gpurun_out/.
+R=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$REPO/gpurun_out/r01
+OUT=$REPO/gpurun_out/$R/final
 mkdir -p $OUT
 cd $REPO
 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --batch 512 --no-cpu > $OUT/bench_b512.json 2>> $OUT/bench_default.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --no-cpu > $OUT/kt_bench.json 2> $OUT/kt.err
+# kernel trace (own run) and the two PMC passes (separate runs, counters only), all of the default bench command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --no-cpu > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
 cd $OUT
-# keep only the small summaries (the traces are large)
-find kt -name "*kernel_stats*.csv" -exec cp {} $OUT/kernel_stats.csv \;
-python3 - <<'PY'
-import csv, glob, json
-def total(d, counter):
-    tot = 0.0; n = 0
-    for f in glob.glob(d + "/**/*counter_collection*.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "k_solve" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                tot += float(r["Counter_Value"]); n += 1
-    return tot, n
-fe, nf = total("pmc_fetch", "FETCH_SIZE"); wr, nw = total("pmc_write", "WRITE_SIZE")
-json.dump({"FETCH_SIZE_KB": fe, "rows_fetch": nf, "WRITE_SIZE_KB": wr, "rows_write": nw}, open("pmc_summary.json", "w"))
-PY
-rm -rf kt pmc_fetch pmc_write
+find kt -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_default.csv \;
+python3 $REPO/tools/pmc_summary.py $OUT $REPO > $OUT/k_solve_pmc_traffic.json
+rm -rf kt pmc_fetch pmc_write pmc_sq
+cd $REPO
+# the reported line: same build, traffic from the passes above (bench.py checks the source hash recorded in the summary)
+python bench.py --traffic-json $OUT/k_solve_pmc_traffic.json > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --batch 512 --no-cpu > $OUT/bench_b512.json 2>> $OUT/bench_default.err
+python bench.py --workload mpc-160 --steps 5 > $OUT/bench_mpc160.json 2>> $OUT/bench_default.err
 ls -la $OUT
