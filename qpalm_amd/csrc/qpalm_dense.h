@@ -549,8 +549,9 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
   (void)lds_bytes;
   __syncthreads();
   for (int i = tid; i < n; i += QP_T) xs[i] = xg[i];
-  /* forward: L y = b */
   long long ts0 = QP_CLOCK();
+  if (fwd_only != 2) { /* 2: x already holds y = L^{-1} b (the forward substitution was fused into the last update sweep) */
+  /* forward: L y = b */
   /* strict lower triangle of a diagonal block into a tile, zero elsewhere (the block solve reads it
    * unconditionally); t0/nt = this thread's index / count among the loading threads */
   auto load_tile = [&](const int J, const int buf, const int t0, const int nt) QP_ALWAYS_INLINE {
@@ -605,8 +606,9 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
     }
     if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[9] += t - ts0; ts0 = t; }
   }
+  }
   __syncthreads();
-  if (fwd_only) {
+  if (fwd_only == 1) {
     for (int i = tid; i < n; i += QP_T) xg[i] = xs[i];
     __syncthreads();
     return;
@@ -725,6 +727,8 @@ struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
   double dd[2][QP_UNB];
+  double ys[2][QP_UNB];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
+  double stash_acc[RPT][64];   /* ... and wavefront 0's own row accumulators while it is the panel wave */
   int prog[2];                 /* helper variant: columns of table [parity] published so far */
 };
 
@@ -751,13 +755,19 @@ template <int RPT, int K>
 /* a real function (own register allocation, see qpalm_device.h): plain pointer arguments, re-typed inside */
 QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *Atss_, const int n_, const int ld_,
                                double *L_, double *Dg_, double *Wst_, const int *cols_, int n_up_,
-                               const int *cols_dn_, int n_dn_, QpShared *S_, char *lds, int64_t *tdbg_, int pre_jmin_ = -1) {
+                               const int *cols_dn_, int n_dn_, QpShared *S_, char *lds, int64_t *tdbg_, int pre_jmin_ = -1,
+                               double *fs_ = nullptr) {
   /* arguments of a real function arrive in VGPRs; these are wave-uniform: back to SGPRs, so that the
    * loops they bound are scalar loops (not exec-mask loops) and v_readlane indices are scalars */
   const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), n_up = QP_UNIFORM(n_up_), n_dn = QP_UNIFORM(n_dn_);
   /* pre_jmin >= 0: ONE rank whose dense vector the caller has already written to Wst[0 .. n) (first nonzero at
    * pre_jmin), sign +1 if n_up == 1 else -1: the trailing update of a KKT row addition / deletion */
   const int pre_jmin = QP_UNIFORM(pre_jmin_);
+  /* fs != NULL: the LAST sweep also does the forward substitution L y = b of the solve that follows (same ascending
+   * column order: an entry of L is used for the substitution right after its last rank has been applied, so the panel
+   * is not streamed a second time for it).  In: b, out: y.  The sweep then starts at column 0. */
+  qp_gdouble *fs = (qp_gdouble *)fs_;
+  const bool fuse_any = QP_UNIFORM((int)(fs_ != nullptr)) != 0;
   int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* the timers live in the kernel's static LDS */
   const qp_gint *Atp = (const qp_gint *)Atp_, *Ati = (const qp_gint *)Ati_, *cols = (const qp_gint *)cols_, *cols_dn = (const qp_gint *)cols_dn_;
   const qp_gdouble *Atss = (const qp_gdouble *)Atss_;
@@ -772,6 +782,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   const int nr = n_up + n_dn;
   for (int r0 = 0; r0 < nr; r0 += K) {
     const int kk = (nr - r0 < K) ? (nr - r0) : K;
+    const bool fuse = fuse_any && (r0 + K >= nr);
     __syncthreads();
     long long tq0 = QP_CLOCK();
     int jmin = n;
@@ -788,6 +799,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         }
       }
     } else jmin = (pre_jmin < n) ? pre_jmin : n - 1;
+    if (fuse) jmin = 0;
     jmin = QP_UNIFORM(block_imin(S, jmin)); /* same value in every lane: keep the block loops scalar */
     double w[RPT][K];
 #pragma unroll
@@ -796,6 +808,9 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
       for (int r = 0; r < K; r++) w[rr][r] = (i < n && r < kk) ? Wst[(size_t)r * n + i] : 0.0;
     }
+    double acc[RPT]; /* fused forward substitution: b_i - sum over the finished columns of l_ij y_j */
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; acc[rr] = (fuse && i < n) ? fs[i] : 0.0; }
     double alpha = 1.0, ialpha = 1.0; /* lane r of wavefront 0 carries alpha_r and 1/alpha_r */
     const int grank = r0 + lane;
     const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
@@ -817,6 +832,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const int bs = (i - J0) / NB;
 #pragma unroll
           for (int r = 0; r < K; r++) U.Wd[bs][(i - J0) % NB][r] = w[rr][r];
+          U.Wd[bs][(i - J0) % NB][K] = acc[rr];
         }
       }
       if (tid < 2) U.prog[tid] = 0;
@@ -830,6 +846,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
           for (int r = 0; r < K; r++) U.stash[rr][r][lane] = w[rr][r];
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) U.stash_acc[rr][lane] = acc[rr];
       }
     }
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1; }
@@ -853,6 +871,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[wslot][lane][r] : 0.0;
+        double accp = (lane < jb) ? U.Wd[wslot][lane][K] : 0.0; /* this row's substitution accumulator (fused solve) */
         if (!QP_UHELP && s > 0) {
           /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
            * deeper queue (one row per lane: registers to spare, and this wave is the critical path) */
@@ -886,6 +905,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 }
               }
               rowp[(size_t)c1 * cstride] = l;
+              if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
               QP_SCHED_BARRIER();
               q[u] = rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
               QP_SCHED_BARRIER();
@@ -956,6 +976,17 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           }
           QP_SCHED_BARRIER();
         }
+        if (fuse) { /* the diagonal block is final: y_J = L_JJ^{-1} (b_J - contributions of the earlier blocks) */
+          double v = accp;
+#pragma unroll 1
+          for (int c = 0; c < jb; c++) {
+            const int ln = QP_FRESH_LANE(lane);
+            const double yc = qp_readlane(v, c);
+            const double lc = (ln > c && ln < jb) ? U.Ld[cur][ln][c] : 0.0;
+            v = QP_FMA(-lc, yc, v);
+          }
+          if (lane < jb) { U.ys[cur][lane] = v; fs[J + lane] = v; }
+        }
         /* diagonal block and pivots back to HBM (each lane re-reads what it wrote itself) */
         if (lane < jb) Dg[J + lane] = dreg;
 #pragma unroll 1
@@ -966,6 +997,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
           for (int r = 0; r < K; r++) w[rr][r] = own_live0 ? U.stash[rr][r][lane] : 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live0 ? U.stash_acc[rr][lane] : 0.0;
         QP_SETPRIO(0);
         if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
       }
@@ -1019,6 +1052,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 QP_SCHED_BARRIER();
               }
               qp_store_rows<RPT>(rowp + (size_t)c1 * cstride, l);
+              if (fuse) { /* column Jp + c1 is final for these rows: its term of the forward substitution */
+                const double yv = U.ys[prv][c1];
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
+              }
               QP_SCHED_BARRIER();
               qp_load_rows<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
               QP_SCHED_BARRIER();
@@ -1035,6 +1073,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           if (i >= Jo && i < Jo + jbo) {
 #pragma unroll
             for (int r = 0; r < K; r++) U.Wd[hslot][i - Jo][r] = w[rr][r];
+            U.Wd[hslot][i - Jo][K] = acc[rr];
           }
         }
         if (wid == 0) {
@@ -1042,6 +1081,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
             for (int r = 0; r < K; r++) U.stash[rr][r][lane] = w[rr][r];
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) U.stash_acc[rr][lane] = acc[rr];
         }
         if (tid == QP_T - 64) tdbg[2] += QP_CLOCK() - tt0; /* the last wavefront's rows live longest */
       }

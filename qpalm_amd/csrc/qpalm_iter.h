@@ -248,9 +248,9 @@ template <int RPT>
 QPN void dev_factor(const qpg_view &V, int n, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, n, V.ld, lds, tdbg); }
 template <int RPT>
 QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, double *Wst, const int *up, int n_up,
-                    const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg) {
+                    const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg, double *fs = nullptr) {
   dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA,
-                                         n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg);
+                                         n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, -1, fs);
 }
 
 /* =============================================================================================
@@ -853,7 +853,14 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, action);
     } else if (la == 2 || la == 4) {
       const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
-      dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg);
+      /* a Newton step solves right after the update: its forward substitution rides on the last sweep */
+      double *fs = nullptr;
+      if (la == 2) {
+        for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1; /* ldlsolveLD_neg_dphi's right-hand side */
+        fs = a.d();
+        __syncthreads();
+      }
+      dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg, fs);
     }
     const long long t1 = QP_CLOCK();
     QP_OPAQUE(a.b);
@@ -864,9 +871,9 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
       if (!V.kkt) {
-        for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
+        if (action != 2) for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
         __syncthreads();
-        dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg);
+        dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg, (action == 2) ? 2 : 0); /* 2: d already holds L^{-1} (-dphi) */
       }
       const long long t2 = QP_CLOCK();
       for (int i = tid; i < m; i += QP_T) a.active_old()[i] = a.active()[i];
