@@ -214,7 +214,9 @@ template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) {
 }
 #endif
 #define QP_FNB 32
+#ifndef QP_FNT
 #define QP_FNT 2 /* row tiles per wavefront and pass of the panel update: 2 keeps accumulators + two fragment stages under 128 VGPRs */
+#endif
 struct FactorLds {
   double Ld[QP_FNB][QP_FNB + 1];
   double dv[QP_FNB];
@@ -1169,6 +1171,148 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         if (lane == 0) { U.prog[cur] = 0; tdbg[13] += QP_CLOCK() - th0; }
       }
       __syncthreads();
+    }
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[7] += tq1 - tq0; tq0 = tq1; }
+  }
+  __syncthreads();
+}
+
+
+/* ---------------------------------------------------------------------------------------------
+ * dense_updown_big: the same multi-rank update (same recurrence, same two FMAs per rank and entry) for factors with more
+ * rows than RPT_max * QP_T = 2048, where the running w of a thread's rows no longer fit its registers (BASELINE.json
+ * config 5: n = 5000).  The K running vectors stay in HBM (Wst, [K][n], read and written once per block column: K n 16
+ * bytes per block against the 2 x 8 x 32 (n - J) of the panel itself) and every thread walks its rows in chunks of QP_T.
+ * No look-ahead: per block column  [panel wave: recurrence on the 32 x 32 diagonal block]  barrier  [all wavefronts:
+ * table applied to the rows below]  barrier.  Throughput is secondary here (one QP of this size keeps a workgroup busy for
+ * seconds anyway); the arithmetic per entry is identical to dense_updown's.
+ * ------------------------------------------------------------------------------------------- */
+template <int K>
+struct UpdownBigLds {
+  double Ld[QP_UNB][QP_UNB + 1];
+  double cwg[QP_UNB][K][2];
+  double Wt[K];
+  double dd[QP_UNB];
+};
+template <int K>
+QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_, const int n_, const int ld_,
+                           double *L_, double *Dg_, double *Wst_, const int *cols_, int n_up_,
+                           const int *cols_dn_, int n_dn_, QpShared *S_, char *lds, int64_t *tdbg_, int pre_jmin_ = -1) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), n_up = QP_UNIFORM(n_up_), n_dn = QP_UNIFORM(n_dn_), pre_jmin = QP_UNIFORM(pre_jmin_);
+  int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_;
+  const qp_gint *Atp = (const qp_gint *)Atp_, *Ati = (const qp_gint *)Ati_, *cols = (const qp_gint *)cols_, *cols_dn = (const qp_gint *)cols_dn_;
+  const qp_gdouble *Atss = (const qp_gdouble *)Atss_;
+  qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_, *Wst = (qp_gdouble *)Wst_;
+  QpShared &S = *S_;
+  typedef UpdownBigLds<K> LdsT;
+  LdsT QP_LDS_AS &U = *QP_LDS_ARG(LdsT, lds);
+  const int NB = QP_UNB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nr = n_up + n_dn;
+  for (int r0 = 0; r0 < nr; r0 += K) {
+    const int kk = (nr - r0 < K) ? (nr - r0) : K;
+    __syncthreads();
+    long long tq0 = QP_CLOCK();
+    int jmin = n;
+    if (pre_jmin < 0) {
+      for (int e = tid; e < kk * n; e += QP_T) Wst[e] = 0.0;
+      __syncthreads();
+      for (int r = wid; r < kk; r += QP_NW) {
+        const int g = r0 + r;
+        const int t = (g < n_up) ? cols[g] : cols_dn[g - n_up];
+        for (int k = Atp[t] + lane; k < Atp[t + 1]; k += 64) {
+          const int i = Ati[k];
+          Wst[(size_t)r * n + i] = Atss[k];
+          jmin = (i < jmin) ? i : jmin;
+        }
+      }
+    } else jmin = (pre_jmin < n) ? pre_jmin : n - 1;
+    jmin = QP_UNIFORM(block_imin(S, jmin));
+    double alpha = 1.0, ialpha = 1.0; /* lane r of wavefront 0 carries alpha_r and 1/alpha_r */
+    const int grank = r0 + lane;
+    const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
+    const int J0 = (jmin / NB) * NB;
+    if (tid == 0) {
+      tdbg[QPG_CNT_SWEEPS] += 1;
+      tdbg[QPG_CNT_SWEEP_ENTRIES] += (long long)(n - J0) * (n - J0 - 1) / 2 + (n - J0);
+    }
+    for (int J = J0; J < n; J += NB) {
+      const int jb = (n - J < NB) ? (n - J) : NB;
+      __syncthreads();
+      for (int e = tid; e < jb * jb; e += QP_T) { /* diagonal block to LDS */
+        const int c1 = e / jb, c = e % jb;
+        if (c > c1) U.Ld[c][c1] = L[(size_t)(J + c1) * ld + (J + c)];
+      }
+      if (tid < jb) U.dd[tid] = Dg[J + tid];
+      __syncthreads();
+      if (wid == 0) { /* panel wave: lane = row of the block, the recurrence of dense_updown */
+        double wrow[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) wrow[r] = (lane < jb && r < kk) ? Wst[(size_t)r * n + J + lane] : 0.0;
+        double dreg = (lane < jb) ? U.dd[lane] : 1.0;
+#pragma unroll 1
+        for (int c1 = 0; c1 < jb; c1++) {
+          const int ln = QP_FRESH_LANE(lane);
+          const double lcur = (ln > c1 && ln < jb) ? U.Ld[ln][c1] : 0.0;
+          if (ln == c1) {
+#pragma unroll
+            for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
+          }
+          QP_WAVE_SYNC();
+          const double wv = (ln < kk) ? U.Wt[ln & (K - 1)] : 0.0;
+          const double d0 = qp_readlane(dreg, c1);
+          const double p = sg * wv * wv * ialpha;
+          double incl = p;
+          if (K > 1) incl += qp_row_shr<1>(incl);
+          if (K > 2) incl += qp_row_shr<2>(incl);
+          if (K > 4) incl += qp_row_shr<4>(incl);
+          if (K > 8) incl += qp_row_shr<8>(incl);
+          const double excl = qp_row_shr<1>(incl);
+          const double dnew = d0 + incl, dprev = d0 + excl;
+          const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
+          const double gam = -sg * wv * ialpha * rdn;
+          if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; }
+          alpha = alpha * dnew * rdp;
+          ialpha = ialpha * dprev * rdn;
+          { const double dfin = qp_readlane(dnew, kk - 1); if (ln == c1) dreg = dfin; }
+          QP_WAVE_SYNC();
+          {
+            double l = lcur;
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+              if (r >= kk) break;
+              wrow[r] = QP_FMA(U.cwg[c1][r][0], l, wrow[r]);
+              l = QP_FMA(U.cwg[c1][r][1], wrow[r], l);
+            }
+            if (ln > c1 && ln < jb) U.Ld[ln][c1] = l;
+          }
+          QP_SCHED_BARRIER();
+        }
+        if (lane < jb) Dg[J + lane] = dreg;
+#pragma unroll 1
+        for (int c = 0; c < jb; c++)
+          if (lane > c && lane < jb) L[(size_t)(J + c) * ld + (J + lane)] = U.Ld[lane][c];
+      }
+      __syncthreads();
+      /* rows below the block: one row per thread and chunk, its K running values from / to HBM */
+      for (int i = J + jb + tid; i < n; i += QP_T) {
+        double w[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) w[r] = (r < kk) ? Wst[(size_t)r * n + i] : 0.0;
+#pragma unroll 1
+        for (int c1 = 0; c1 < jb; c1++) {
+          double l = L[(size_t)(J + c1) * ld + i];
+#pragma unroll
+          for (int r = 0; r < K; r++) {
+            if (r >= kk) break;
+            w[r] = QP_FMA(U.cwg[c1][r][0], l, w[r]);
+            l = QP_FMA(U.cwg[c1][r][1], w[r], l);
+          }
+          L[(size_t)(J + c1) * ld + i] = l;
+        }
+#pragma unroll
+        for (int r = 0; r < K; r++) if (r < kk) Wst[(size_t)r * n + i] = w[r];
+      }
     }
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[7] += tq1 - tq0; tq0 = tq1; }
   }

@@ -246,11 +246,15 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
  * =========================================================================================== */
 template <int RPT>
 QPN void dev_factor(const qpg_view &V, int n, double *L, double *Dg, char *lds, int64_t *tdbg) { dense_factor<RPT>(L, Dg, n, V.ld, lds, tdbg); }
+/* RPT = rows of the factor per thread in the update sweep (registers); RPT == 0 is the large-factor form (more than
+ * 4 QP_T rows: the running vectors live in HBM, dense_updown_big) */
 template <int RPT>
 QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, double *Wst, const int *up, int n_up,
-                    const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg, double *fs = nullptr) {
-  dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA,
-                                         n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, -1, fs);
+                    const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg, double *fs = nullptr, int pre_jmin = -1) {
+  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
+  const double *Atss = V.Atss + (size_t)b * V.nnzA;
+  if constexpr (RPT == 0) dense_updown_big<16>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin);
+  else dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin, fs);
 }
 
 /* =============================================================================================
@@ -855,7 +859,8 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
       /* a Newton step solves right after the update: its forward substitution rides on the last sweep */
       double *fs = nullptr;
-      if (la == 2) {
+      constexpr bool FUSED = (RPT > 0); /* the large-factor sweep keeps the solve separate */
+      if (FUSED && la == 2) {
         for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1; /* ldlsolveLD_neg_dphi's right-hand side */
         fs = a.d();
         __syncthreads();
@@ -871,9 +876,10 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
       if (!V.kkt) {
-        if (action != 2) for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
+        const bool fused = (RPT > 0) && (action == 2);
+        if (!fused) for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
         __syncthreads();
-        dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg, (action == 2) ? 2 : 0); /* 2: d already holds L^{-1} (-dphi) */
+        dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg, fused ? 2 : 0); /* 2: d already holds L^{-1} (-dphi) */
       }
       const long long t2 = QP_CLOCK();
       for (int i = tid; i < m; i += QP_T) a.active_old()[i] = a.active()[i];

@@ -80,12 +80,16 @@ struct LobpcgShared { double g[QP_T]; double y[3]; double lambda; double scal; }
 
 QPD double lob_dot(LobpcgShared &S, const double *u, const double *v, int n) { /* vec_prod, lin_alg.c:72-86 */
   const int ng = n / 4, tid = threadIdx.x;
-  __syncthreads();
-  for (int k = tid; k < ng; k += QP_T) { const int i = 4 * k; S.g[k] = (u[i] * v[i] + u[i + 1] * v[i + 1] + u[i + 2] * v[i + 2] + u[i + 3] * v[i + 3]); }
+  double prod = 0.0; /* thread 0's running total: the groups are added in index order, QP_T of them per round */
+  for (int k0 = 0; k0 < ng; k0 += QP_T) {
+    __syncthreads();
+    const int k = k0 + tid;
+    if (k < ng) { const int i = 4 * k; S.g[tid] = (u[i] * v[i] + u[i + 1] * v[i + 1] + u[i + 2] * v[i + 2] + u[i + 3] * v[i + 3]); }
+    __syncthreads();
+    if (tid == 0) { const int cnt = (ng - k0 < QP_T) ? (ng - k0) : QP_T; for (int q = 0; q < cnt; q++) prod += S.g[q]; }
+  }
   __syncthreads();
   if (tid == 0) {
-    double prod = 0.0;
-    for (int k = 0; k < ng; k++) prod += S.g[k];
     for (int i = 4 * ng; i < n; i++) prod += u[i] * v[i];
     S.scal = prod;
   }

@@ -84,7 +84,6 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
   const size_t sk = (size_t)V.n + V.m; /* batch strides */
   double *sol = V.kkt_sol + (size_t)b * sk, *rhs = V.kkt_rhs + (size_t)b * sk, *z = V.kkt_tmp + (size_t)b * sk;
   int *state = V.kkt_state + (size_t)b * V.m;
-  constexpr int K = (RPT <= 2 ? 16 : 8);
   if (action == 1) {
     kkt_form(V, a, b, L, gamma, prox);
     dense_factor<RPT>(L, Dg, np, ld, lds, I.s.ticks_dbg);
@@ -139,7 +138,7 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
       __syncthreads();
       /* trailing block: one rank-1 sweep over the columns after p */
       if (p + 1 < np)
-        dense_updown<RPT, K>(nullptr, nullptr, nullptr, np, ld, L, Dg, Wst, nullptr, up ? 1 : 0, nullptr, up ? 0 : 1, &I.S, lds, I.s.ticks_dbg, p + 1);
+        dev_updown<RPT>(V, b, np, L, Dg, Wst, nullptr, up ? 1 : 0, nullptr, up ? 0 : 1, I.S, lds, I.s.ticks_dbg, nullptr, p + 1);
     }
     if (tid == 0) I.s.n_rank1 += ne + nl;
   }

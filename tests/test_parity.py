@@ -583,3 +583,14 @@ def test_warm_started_mpc_sequence(ctx):
         q.solve(); o.solve()
         assert q.status_val == o.status_val and int(q.info.iter) == int(o.info.iter)
         assert rel(q.x, o.x) <= RTOL and rel(q.y, o.y) <= RTOL
+
+
+def test_large_factor_path(ctx):
+    """Factors with more rows than 4 x workgroup size use the large-factor update sweep (running vectors in HBM,
+    dense_updown_big / k_solve<0>): n = 530 on the emulator (workgroups of 128 threads there), n = 2500 on the GPU
+    (workgroups of 512 threads: above the 2048-row limit of the register-resident sweep; BASELINE.json config 5 is n = 5000)."""
+    n, m = sizes(ctx, (530, 700), (2500, 3200))
+    p = random_qp(n, m, seed=11, density_A=sizes(ctx, 0.02, 0.004), density_M=sizes(ctx, 0.01, 0.002))
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    bt = _compare_solve(ctx, [p], st)
+    assert int(bt.stats(0).n_rank1) > 0 and int(bt.stats(0).n_sweeps) > 0
