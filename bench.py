@@ -354,7 +354,8 @@ def worker(args):
     phases["factor"]["TFLOPs"] = phases["factor"]["flop"] / (max(phase_ms["factor"], 1e-9) * 1e-3 * B / conc) / 1e12
     rc = 0
     if rank == 0:
-        copy_gbs = ctx.hbm_copy_gbs(1 << 30, 5)             # attainable ceiling on this box (read + write)
+        copy_gbs = ctx.hbm_copy_gbs(1 << 30, 5)             # attainable ceilings on this box: copy (read + write) ...
+        read_gbs = ctx.hbm_read_gbs(1 << 30, 5)             # ... and a read-only stream
         model0 = byte_model(n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1]))
         nsl = min(B, RESIDENT_WORKGROUPS)
         ms_ldl = bt.ldlsolve_all(reps=4)                    # stand-alone LDL' solve kernel ("HBM GB/s on LDL")
@@ -381,13 +382,13 @@ def worker(args):
             "roofline": {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes,
-                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
+                         "measured_copy_GBps": copy_gbs, "measured_read_GBps": read_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "bytes_note": "update bytes = 16 B x entries of L[:, J0:] actually swept (device counter), not the 8d upper bound",
                          "phases": phases},
             "ldl_solve": {"kernel": "k_ldlsolve_all", "qps": nsl, "ms": ms_ldl, "bytes": ldl_bytes,
                           "achieved": ldl_bytes / (ms_ldl * 1e-3) / 1e9, "unit": "GB/s",
                           "frac": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "frac_of_measured_copy": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / copy_gbs},
+                          "frac_of_measured_read": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / read_gbs},
             "solve_stats": {"all_solved": n_bad == 0, "kkt_spot_check_worst_rel": kkt,
                             "iter_mean": float(iters.mean()), "iter_max": int(iters.max()),
                             "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve", "sweep_entries")},

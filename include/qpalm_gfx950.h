@@ -195,6 +195,7 @@ int qpg_batch_ldlsolve_all(qpg_batch *bt, qpg_int reps, float *ms_per_rep);
 /* attainable HBM bandwidth of this device, measured with a plain copy kernel (best of `reps` copies of `bytes` bytes;
  * read + write counted): the yardstick quoted next to the 8 TB/s spec figure */
 int qpg_ctx_hbm_copy_gbs(qpg_ctx *ctx, size_t bytes, qpg_int reps, float *gbs);
+int qpg_ctx_hbm_read_gbs(qpg_ctx *ctx, size_t bytes, qpg_int reps, float *gbs); /* read-only stream (the LDL' solve only reads L) */
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,7 @@ def load(path=None):
     L.qpg_sparse_matvec.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf, C.c_int, C.c_int, pf, pf]
     L.qpg_batch_ldlsolve_all.argtypes = [C.c_void_p, c_int, C.POINTER(C.c_float)]
     L.qpg_ctx_hbm_copy_gbs.argtypes = [C.c_void_p, C.c_size_t, c_int, C.POINTER(C.c_float)]
+    L.qpg_ctx_hbm_read_gbs.argtypes = [C.c_void_p, C.c_size_t, c_int, C.POINTER(C.c_float)]
     _LIBS[path] = L
     return L
 
@@ -130,7 +131,7 @@ SYMBOLS = [
     "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints", "qpg_ldldowndate_leaving_constraints",
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
     "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
-    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_batch_set_problem_sized",
+    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_ctx_hbm_read_gbs", "qpg_batch_set_problem_sized",
 ]
 
 

@@ -422,25 +422,37 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_ldlsolve_all(qpg_view V, 
   }
 }
 
-/* Plain HBM copy (16 bytes per lane and step, grid-stride): the attainable-bandwidth yardstick that bench.py quotes
- * next to the 8 TB/s spec figure ("measure the attainable ceiling on the box"). */
+/* HBM yardsticks quoted by bench.py next to the 8 TB/s spec figure ("measure the attainable
+ * ceiling on the box"): a copy (read + write; every workgroup streams contiguous 32 KB pieces, eight 16-byte loads in
+ * flight per lane -- the best of the forms in tools/copybench.hip, ~5.4 TB/s) and a read-only stream (~6.5 TB/s). */
 __global__ __launch_bounds__(256) void k_hbm_copy(const double *__restrict__ src, double *__restrict__ dst, size_t npairs) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
 #ifdef QPALM_EMU
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) { dst[2 * i] = src[2 * i]; dst[2 * i + 1] = src[2 * i + 1]; }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) { dst[2 * i] = src[2 * i]; dst[2 * i + 1] = src[2 * i + 1]; }
 #else
   typedef double copy_d2 __attribute__((ext_vector_type(2)));
   const copy_d2 *s2 = (const copy_d2 *)src;
   copy_d2 *d2 = (copy_d2 *)dst;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < npairs; i += 4 * stride) { /* four independent 16-byte loads in flight per lane */
-    const copy_d2 a = __builtin_nontemporal_load(s2 + i), b = __builtin_nontemporal_load(s2 + i + stride);
-    const copy_d2 c = __builtin_nontemporal_load(s2 + i + 2 * stride), d = __builtin_nontemporal_load(s2 + i + 3 * stride);
-    __builtin_nontemporal_store(a, d2 + i); __builtin_nontemporal_store(b, d2 + i + stride);
-    __builtin_nontemporal_store(c, d2 + i + 2 * stride); __builtin_nontemporal_store(d, d2 + i + 3 * stride);
+  constexpr int U = 8;
+  const size_t per = (size_t)U * 256;
+  for (size_t base = (size_t)blockIdx.x * per; base < npairs; base += (size_t)gridDim.x * per) {
+    copy_d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const size_t i = base + u * 256 + threadIdx.x; v[u] = (i < npairs) ? s2[i] : copy_d2{0, 0}; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { const size_t i = base + u * 256 + threadIdx.x; if (i < npairs) d2[i] = v[u]; }
   }
-  for (; i < npairs; i += stride) d2[i] = s2[i];
 #endif
+}
+__global__ __launch_bounds__(256) void k_hbm_read(const double *__restrict__ src, double *__restrict__ out, size_t npairs) {
+  double acc = 0.0;
+#ifdef QPALM_EMU
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) acc += src[2 * i] + src[2 * i + 1];
+#else
+  typedef double copy_d2 __attribute__((ext_vector_type(2)));
+  const copy_d2 *s2 = (const copy_d2 *)src;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) { const copy_d2 v = s2[i]; acc += v.x + v.y; }
+#endif
+  if (acc == 1.234567) out[0] = acc; /* keeps the loads alive */
 }
 
 #endif

@@ -53,6 +53,14 @@ class Context:
             raise QpgError(rc, self.L.qpg_last_error().decode())
         return float(g.value)
 
+    def hbm_read_gbs(self, nbytes=1 << 30, reps=5):
+        """measured read-only streaming bandwidth of the device (GB/s)"""
+        g = C.c_float(0.0)
+        rc = self.L.qpg_ctx_hbm_read_gbs(self.h, int(nbytes), int(reps), C.byref(g))
+        if rc != 0:
+            raise QpgError(rc, self.L.qpg_last_error().decode())
+        return float(g.value)
+
     def close(self):
         if self.h:
             self.L.qpg_ctx_destroy(self.h)
