@@ -718,6 +718,12 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
 #ifndef QP_UHELP
 #define QP_UHELP 0 /* 1: wavefront 1 applies the look-ahead rows column by column behind the panel wave */
 #endif
+#ifndef QP_PSPLIT
+#define QP_PSPLIT 0 /* 1: the panel wave splits the ranks of the block recurrence over its two half-waves (see dense_updown).
+                       Parity-green, but measured SLOWER on MI355X (panel wave 78 vs 61 ms per QP): a wavefront issues one
+                       fp64 VALU op per ~5 clk dependent or not, and the split's extra selects / addresses outweigh the
+                       16 FMAs it takes off each step.  Kept as an opt-in experiment (-DQP_PSPLIT=1). */
+#endif
 #ifndef QP_TQD
 #define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
 #endif
@@ -728,6 +734,7 @@ struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block
   double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
+  double czero[K][2];          /* an all-zero table column: what an idle half-wave of the rank-split panel wave reads (exact no-ops) */
   double dd[2][QP_UNB];
   double ys[2][QP_UNB];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
   double stash_acc[RPT][64];   /* ... and wavefront 0's own row accumulators while it is the panel wave */
@@ -838,6 +845,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         }
       }
       if (tid < 2) U.prog[tid] = 0;
+      if (tid < 2 * K) (&U.czero[0][0])[tid] = 0.0;
       for (int e = tid; e < jb0 * jb0; e += QP_T) {
         const int c1 = e / jb0, c = e % jb0;
         if (c > c1) U.Ld[0][c][c1] = L[(size_t)(J0 + c1) * ld + (J0 + c)];
@@ -870,6 +878,130 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         /* ===== panel wave ===================================================================== */
         const long long tp0 = QP_CLOCK();
         QP_SETPRIO(3); /* the serial chain of the sweep goes first on its SIMD */
+#if QP_PSPLIT
+        /* ---- rank-split panel wave.  The block has 32 rows but a wavefront has 64 lanes: the low half-wave works on
+         * ranks 0 .. H-1 (H = K/2) of column t while the high half-wave works on ranks H .. K-1 of column t-1 (the
+         * (column, rank) dependences of the recurrence form a grid: stage B of a column only needs stage A of the same
+         * column and stage B of the column before).  Per step the serial chain is H ranks = 2H dependent FMAs instead of
+         * 2K, the rank scalars of both stages are computed together (two DPP rows: lanes 0..H-1 and 16..16+H-1), the
+         * pivot-row transposition writes 2 x H values; a block takes jb + 1 steps.  Every entry still gets exactly the
+         * same FMAs in the same order (ranks ascending per column). ------------------------------------------------- */
+        constexpr int H = K / 2;
+        static_assert(!QP_UHELP, "the helper-wave variant belongs to the unsplit panel wave");
+        const int hi = lane >> 5, prow = lane & 31, roff = hi * H;
+        double wr[H];
+#pragma unroll
+        for (int r = 0; r < H; r++) wr[r] = (prow < jb) ? U.Wd[wslot][prow][roff + r] : 0.0;
+        double accp = (prow < jb) ? U.Wd[wslot][prow][K] : 0.0; /* this row's substitution accumulator (fused solve) */
+        if (s > 0) {
+          /* table s-1 applied to the rows of block s, same split: step u = low half on column u (l from HBM through a
+           * register queue), high half on column u-1 (l handed over by the low half), which also stores the final l */
+          constexpr int QD = 8;
+          const bool ldl = (hi == 0 && prow < jb);
+          qp_gdouble *rowp = ldl ? (L + (size_t)Jp * ld + J + prow) : (dummy + lane);
+          const size_t cstride = ldl ? (size_t)ld : 0;
+          const bool stl = (hi == 1 && prow < jb);
+          qp_gdouble *rows = stl ? (L + (size_t)Jp * ld + J + prow) : (dummy + lane);
+          const size_t sstride = stl ? (size_t)ld : 0;
+          double q[QD];
+#pragma unroll
+          for (int cc = 0; cc < QD; cc++) q[cc] = rowp[(size_t)cc * cstride];
+          double lmid = 0.0; /* high half: l of column u-1 after the first H ranks */
+          auto step = [&](const int u, const double lq) QP_ALWAYS_INLINE {
+            const int col = u - hi; /* this half's column; -1 (high half, first step) and NB (low half, last step) are idle */
+            const bool act = (col >= 0 && col < NB);
+            const double QP_LDS_AS *tab = act ? &U.cwg[prv][col][roff][0] : &U.czero[0][0];
+            double l = hi ? lmid : lq;
+#pragma unroll
+            for (int r = 0; r < H; r++) {
+              wr[r] = QP_FMA(tab[2 * r], l, wr[r]);
+              l = QP_FMA(tab[2 * r + 1], wr[r], l);
+            }
+            if (hi && act) {
+              rows[(size_t)col * sstride] = l;
+              if (fuse) accp = QP_FMA(-l, U.ys[prv][col], accp); /* column Jp + col is final for this row */
+            }
+            lmid = __shfl(l, prow); /* the low half's l goes to the same row of the high half */
+          };
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
+#pragma unroll
+            for (int u = 0; u < QD; u++) {
+              const int c1 = c0 + u;
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+              step(c1, q[u]);
+              QP_SCHED_BARRIER();
+              q[u] = rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free */
+              QP_SCHED_BARRIER();
+            }
+          };
+          group(0);
+#pragma unroll 1
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+          step(NB, 0.0); /* drains the high half (column NB - 1) */
+          accp = __shfl(accp, prow + 32); /* the accumulators were kept by the high half: back to lane = row */
+        }
+        double dreg = (lane < jb) ? U.dd[cur][lane] : 1.0;          /* lane c holds the pivot of column c */
+        double dout = dreg;
+        double lnext = (lane > 0 && lane < jb) ? U.Ld[cur][lane][0] : 0.0; /* low half: original l of the coming column */
+        double lmid = 0.0, dmid = 1.0;
+        /* rank of this lane when it computes rank scalars: lanes 0..H-1 -> ranks 0..H-1 (stage A), 16..16+H-1 -> H..K-1 (B) */
+        const int sl = lane & 15, srow = lane >> 4;
+        const int srank = (srow == 0) ? sl : H + sl;
+        const bool sact = (srow < 2 && sl < H);
+        const double sg2 = (sact && srank < kk) ? ((r0 + srank < n_up) ? 1.0 : -1.0) : 0.0;
+#pragma unroll 1
+        for (int t = 0; t <= jb; t++) {
+          const int ln = QP_FRESH_LANE(lane);
+          const int lrow = ln & 31, lhi = ln >> 5;
+          const double lcur = lnext;
+          lnext = (ln > t + 1 && ln < jb) ? U.Ld[cur][ln][t + 1] : 0.0; /* in flight during this step */
+          /* pivot rows to lane = rank: row t from the low half (ranks 0..H-1), row t-1 from the high half (H..K-1) */
+          if (lrow == t - lhi && lrow < jb) {
+#pragma unroll
+            for (int r = 0; r < H; r++) U.Wt[lhi * H + r] = wr[r];
+          }
+          QP_WAVE_SYNC();
+          const bool sA = ((ln >> 4) == 0), s_on = ((ln >> 4) < 2) && ((ln & 15) < H);
+          const int rk = sA ? (ln & 15) : H + (ln & 15);
+          const bool colA = (t < jb), colB = (t >= 1);
+          const double wv = (s_on && rk < kk && (sA ? colA : colB)) ? U.Wt[rk & (K - 1)] : 0.0;
+          const double d0a = colA ? qp_readlane(dreg, (t < jb) ? t : 0) : 1.0;
+          const double d0 = sA ? d0a : (colB ? dmid : 1.0);
+          const double p = sg2 * wv * wv * ialpha;
+          double incl = p;
+          if (H > 1) incl += qp_row_shr<1>(incl);
+          if (H > 2) incl += qp_row_shr<2>(incl);
+          if (H > 4) incl += qp_row_shr<4>(incl);
+          const double excl = qp_row_shr<1>(incl);
+          const double dnew = d0 + incl, dprev = d0 + excl;
+          const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
+          const double gam = -sg2 * wv * ialpha * rdn;
+          if (s_on && (sA ? colA : colB)) { const int tc = sA ? t : t - 1; U.cwg[cur][tc][rk][0] = -wv; U.cwg[cur][tc][rk][1] = -gam; }
+          alpha = alpha * dnew * rdp;
+          ialpha = ialpha * dprev * rdn;
+          const double dA = qp_readlane(dnew, H - 1);      /* column t after the first H ranks */
+          const double dB = qp_readlane(dnew, 16 + H - 1); /* column t-1 after all ranks: its final pivot */
+          if (colB && ln == t - 1) dout = dB;
+          dmid = dA;
+          QP_WAVE_SYNC();
+          {
+            const int col = t - lhi;
+            const bool act = (col >= 0 && col < jb);
+            const double QP_LDS_AS *tab = act ? &U.cwg[cur][col][lhi * H][0] : &U.czero[0][0];
+            double l = lhi ? lmid : lcur;
+#pragma unroll
+            for (int r = 0; r < H; r++) {
+              wr[r] = QP_FMA(tab[2 * r], l, wr[r]);
+              l = QP_FMA(tab[2 * r + 1], wr[r], l);
+            }
+            if (lhi && act && lrow > col && lrow < jb) U.Ld[cur][lrow][col] = l; /* final entry of the diagonal block */
+            lmid = __shfl(l, lrow);
+          }
+          QP_SCHED_BARRIER();
+        }
+        dreg = dout;
+        QP_WAVE_SYNC(); /* the final block entries were written by the high half-wave, the code below reads them lane = row */
+#else
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[wslot][lane][r] : 0.0;
@@ -978,6 +1110,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           }
           QP_SCHED_BARRIER();
         }
+#endif
         if (fuse) { /* the diagonal block is final: y_J = L_JJ^{-1} (b_J - contributions of the earlier blocks) */
           double v = accp;
 #pragma unroll 1
