@@ -31,7 +31,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-RESIDENT_WORKGROUPS = 512  # 2 workgroups per CU x 256 CUs (QP_WAVES_PER_SIMD = 4)
 
 
 def source_sha256():
@@ -60,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--m", type=int, default=0, help="random workload: number of constraints (default 2 n)")
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
+    ap.add_argument("--place-panel-wave", type=int, default=1, help="0: every workgroup runs its serial chains on wavefront 0 (A/B of the SIMD placement)")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
     ap.add_argument("--traffic-json", default=DEFAULT_TRAFFIC_JSON,
@@ -234,6 +235,10 @@ def worker(args):
     ctx.set_option("update_rank_threshold", args.rank_threshold)
     if args.max_slots:
         ctx.set_option("max_slots", args.max_slots)
+    if not args.small_workgroups:
+        ctx.set_option("small_workgroups", 0)
+    if not args.place_panel_wave:
+        ctx.set_option("place_panel_wave", 0)
     B = args.batch
     settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     rng = np.random.default_rng(12345 + rank)
@@ -338,7 +343,7 @@ def worker(args):
     phase_ms = {"total": mean(lambda s: s.ms_total), "factor": mean(lambda s: s.ms_factor), "update": mean(lambda s: s.ms_update),
                 "solve": mean(lambda s: s.ms_solve), "linesearch": mean(lambda s: s.ms_linesearch), "residuals": mean(lambda s: s.ms_dbg[12])}
     phase_ms["dbg"] = [mean(lambda s, k=k: s.ms_dbg[k]) for k in range(16)]
-    conc = min(B, RESIDENT_WORKGROUPS if not args.max_slots else args.max_slots)
+    conc, wg_threads, wg_lds = bt.launch_shape()
     # aggregate GB/s of a phase = bytes of all QPs / (time the phase occupies one of `conc` concurrent workgroups)
     def phase_gbs(nbytes, ms_per_qp):
         return nbytes / (max(ms_per_qp, 1e-9) * 1e-3 * B / conc) / 1e9
@@ -357,7 +362,7 @@ def worker(args):
         copy_gbs = ctx.hbm_copy_gbs(1 << 30, 5)             # attainable ceilings on this box: copy (read + write) ...
         read_gbs = ctx.hbm_read_gbs(1 << 30, 5)             # ... and a read-only stream
         model0 = byte_model(n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1]))
-        nsl = min(B, RESIDENT_WORKGROUPS)
+        nsl = conc
         ms_ldl = bt.ldlsolve_all(reps=4)                    # stand-alone LDL' solve kernel ("HBM GB/s on LDL")
         ldl_bytes = nsl * model0["b_solve"]
         traffic = None
@@ -378,7 +383,8 @@ def worker(args):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "parallelism": "batch-shard x%d" % world,
-                       "update_rank_threshold": args.rank_threshold},
+                       "update_rank_threshold": args.rank_threshold,
+                       "workgroups": conc, "threads_per_workgroup": wg_threads, "lds_per_workgroup": wg_lds},
             "roofline": {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes,

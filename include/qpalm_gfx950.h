@@ -114,6 +114,8 @@ typedef struct {
   qpg_int sweep_entries;         /* entries of L the rank-update sweeps touched (each read and written once): sum of nnz(L[:, J0:]) */
   qpg_int factor_reread_entries; /* entries of L re-read by the panel updates of the factorisations (beyond the compulsory write) */
   qpg_float lobpcg_lambda;       /* nonconvex QPs: the eigenvalue bound of lobpcg (nonconvex.c:29-168); gamma_init = gamma_max = 1/|lambda| */
+  qpg_int placement;             /* where the QP's last solve ran: (XCC, SE, SH, CU) key << 16 | arrival index of the workgroup on
+                                    that CU << 8 | panel wavefront << 4 | SIMD of wavefront 0 (qp_place_panel_wave) */
   qpg_int lobpcg_iter, nonconvex; /* LOBPCG iterations; settings->nonconvex of THIS QP after set_settings_nonconvex (:171-183) */
 } QPGStats;
 
@@ -153,6 +155,10 @@ int  qpg_batch_iterate(qpg_batch *bt, qpg_int k);                  /* at most k 
 int  qpg_batch_begin_solve(qpg_batch *bt);                         /* start of a qpalm_solve driven by qpg_batch_iterate: finished QPs start over */
 int  qpg_batch_last_solve_ms(qpg_batch *bt, float *ms);            /* HIP-event time of the last solve/iterate launch */
 int  qpg_batch_num_unfinished(qpg_batch *bt, qpg_int *count);
+/* how the batch runs: concurrent workgroups (= resident factor panels), threads per workgroup (512, or 256 for QPs whose
+ * factor has at most 256 rows -- four workgroups per CU instead of two), dynamic LDS per workgroup.  No reference
+ * counterpart (the reference runs one QP on one core); used by bench.py's per-phase bandwidth figures. */
+int  qpg_batch_launch_shape(qpg_batch *bt, qpg_int *workgroups, qpg_int *threads, qpg_int *lds_bytes);
 int  qpg_batch_update_settings(qpg_batch *bt, const QPGSettings *s);
 int  qpg_batch_update_bounds(qpg_batch *bt, const qpg_float *bmin, const qpg_float *bmax); /* [B][m] or NULL */
 int  qpg_batch_update_q(qpg_batch *bt, const qpg_float *q);                              /* [B][n] */

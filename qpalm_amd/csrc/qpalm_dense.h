@@ -58,6 +58,9 @@ QPD double qp_readlane(double v, int src) { /* src is wave-uniform: v_readlane_b
 
 /* 1/x to (almost) full fp64 precision: v_rcp_f64 + two Newton steps; avoids the ~28-instruction
  * IEEE division sequence on the serial chain of the update recurrence */
+#ifndef QP_PANEL_TIMING
+#define QP_PANEL_TIMING 0 /* 1 (diagnostic build): ms_dbg[8..11] = panel wave: rows of the block / recurrence / solve + write-back / barrier wait */
+#endif
 #ifdef QPALM_EMU
 QPD double qp_rcp(double x) { return 1.0 / x; }
 #else
@@ -242,7 +245,9 @@ struct FactorLds {
 #ifndef QP_NI_FGEMM
 #define QP_NI_FGEMM QPNI
 #endif
-#define QP_FKC 32 /* columns per staged chunk (J and the k ranges are multiples of it) */
+#ifndef QP_FKC
+#define QP_FKC 32 /* columns per staged chunk (J and the k ranges are multiples of it); 16 in the 256-thread instance (LDS budget) */
+#endif
 #define QP_FAS 66 /* row stride of the staged operand in doubles: 64 block rows + 2 (16-byte aligned, spreads the four k rows of a fragment over the banks) */
 #ifndef QP_FST
 #define QP_FST 4 /* panel fragments (k steps of 4 columns) in flight per wavefront; divides QP_FKC / 4 */
@@ -593,7 +598,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
       if (QP_NW == 1 && J + NB < n) load_tile(J + NB, cur ^ 1, tid, QP_T);
     }
     __syncthreads();
-    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[8] += t - ts0; ts0 = t; }
+    if (!QP_PANEL_TIMING && tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[8] += t - ts0; ts0 = t; }
     for (int i = J + jb + tid; i < n; i += QP_T) { /* QP_SOLVE_FCH independent column loads in flight per row */
       double acc = xs[i];
 #pragma unroll
@@ -606,7 +611,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
       }
       xs[i] = acc;
     }
-    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[9] += t - ts0; ts0 = t; }
+    if (!QP_PANEL_TIMING && tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[9] += t - ts0; ts0 = t; }
   }
   }
   __syncthreads();
@@ -658,7 +663,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
         if (lane == 0 && c < jb) T.part[c] = sv;
       }
     }
-    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[10] += t - ts0; ts0 = t; }
+    if (!QP_PANEL_TIMING && tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[10] += t - ts0; ts0 = t; }
 #pragma unroll
     for (int k = 0; k < TE; k++) {
       const int e = tid + k * QP_T, c = e / NB, r = e % NB;
@@ -686,7 +691,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
       if (lane < jb) xs[J + lane] = v;
     }
     __syncthreads();
-    if (tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[11] += t - ts0; ts0 = t; }
+    if (!QP_PANEL_TIMING && tdbg && tid == 0) { const long long t = QP_CLOCK(); tdbg[11] += t - ts0; ts0 = t; }
   }
   for (int i = tid; i < n; i += QP_T) xg[i] = xs[i];
   __syncthreads();
@@ -724,12 +729,18 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
                        fp64 VALU op per ~5 clk dependent or not, and the split's extra selects / addresses outweigh the
                        16 FMAs it takes off each step.  Kept as an opt-in experiment (-DQP_PSPLIT=1). */
 #endif
+#ifndef QP_USQ
+#define QP_USQ 1 /* 1: the owners stage the square L(block s+1 rows, block s columns) in LDS one phase ahead and write the finished
+                    diagonal blocks back, so that the panel wave (the serial chain of the sweep) never waits for HBM; costs
+                    16 KB of LDS.  0: the panel wave streams that square from HBM itself (the 256-thread instance: 38 KB LDS). */
+#endif
 #ifndef QP_TQD
 #define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
 #endif
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
   double Ld[2][QP_UNB][QP_UNB + 1];
+  double Lsq[(QP_USQ && !QP_UHELP) ? 2 : 1][QP_USQ ? QP_UNB : 1][QP_UNB]; /* [parity][column of block s-1][row of block s]: the square under diagonal block s-1 */
   double Wd[QP_UHELP ? 3 : 2][QP_UNB][K + 1]; /* running w of the rows of block b: owners -> (helper wave ->) panel wave */
   double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
@@ -782,12 +793,16 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   const qp_gdouble *Atss = (const qp_gdouble *)Atss_;
   qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_, *Wst = (qp_gdouble *)Wst_;
   QpShared &S = *S_; /* static LDS of the kernel, reached through a generic pointer (one small reduction) */
-  static_assert(K <= 16, "rank block must fit one DPP row");
+  static_assert(K == 8 || K == 16, "rank block: one DPP row, groups of eight ranks");
   typedef UpdownLds<RPT, K> UpdownLdsT;
   UpdownLdsT QP_LDS_AS &U = *QP_LDS_ARG(UpdownLdsT, lds);
-  static_assert(sizeof(UpdownLds<RPT, K>) <= 64 * 1024, "update scratch must fit the dynamic LDS (lds_bytes >= 64 KB)");
+  static_assert(sizeof(UpdownLds<RPT, K>) <= QPG_LDS_DEFAULT, "update scratch must fit the dynamic LDS (lds_bytes >= QPG_LDS_DEFAULT)");
+  static_assert(!(QP_USQ && QP_PSPLIT), "the staged square belongs to the default panel wave");
+  static_assert(!QP_UHELP || (QP_USQ && QP_NW >= 2), "the helper-wave variant parks columns in the staged square's LDS");
   const int NB = QP_UNB;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  /* wavefront numbering rotated so that "wavefront 0" below (panel wave, owner of the first rows) is the wavefront
+   * qp_place_panel_wave picked for this workgroup; rows are owned by the ROTATED thread id throughout the sweep */
+  const int lane = threadIdx.x & 63, wid = QP_UNIFORM((int)((threadIdx.x >> 6) - S.panel_wave) & (QP_NW - 1)), tid = wid * 64 + lane;
   const int nr = n_up + n_dn;
   for (int r0 = 0; r0 < nr; r0 += K) {
     const int kk = (nr - r0 < K) ? (nr - r0) : K;
@@ -868,6 +883,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       const int jbn = (n - Jn < NB) ? ((n - Jn > 0) ? (n - Jn) : 0) : NB; /* 0 when block s is the last one */
       const int cur = s & 1, prv = cur ^ 1;
       const long long tph0 = QP_CLOCK();
+      long long tpe = tph0;
       /* owners work on rows from Jo on and hand block Jo over: the block after this one, or (helper
        * variant) the one after that */
       const int Jo = QP_UHELP ? Jn + NB : Jn;
@@ -1009,48 +1025,90 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         if (!QP_UHELP && s > 0) {
           /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
            * deeper queue (one row per lane: registers to spare, and this wave is the critical path) */
-          constexpr int QD = 8;
+          constexpr int QD = QP_USQ ? 4 : 8;
           qp_gdouble *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
           const size_t cstride = (lane < jb) ? (size_t)ld : 0;
+          const int lrow = lane & (NB - 1);
           double q[QD];
 #pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[cc] = rowp[(size_t)cc * cstride];
+          for (int cc = 0; cc < QD; cc++) q[cc] = QP_USQ ? U.Lsq[cur][cc][lrow] : rowp[(size_t)cc * cstride];
           /* unrolled by the queue depth: slot u of the queue is a fixed register, so the load
            * issued QD columns ago is the only one waited for (rotating the queue through register
-           * moves would make every column wait for the newest load) */
-          auto group = [&](const int c0) QP_ALWAYS_INLINE {
+           * moves would make every column wait for the newest load).
+           * The (-w_j, -gamma) pairs are software-pipelined by hand with register rotation, eight ranks (one "half-step")
+           * deep: right after the two FMAs of a rank have consumed its pair, the same registers are refilled with the pair
+           * of that rank slot in the NEXT half-step, so every LDS read has 16 dependent FMAs of cover and no second buffer
+           * is needed (left to the compiler, the eight reads of a half-step are issued together and waited for: ~600 clk
+           * per column measured against ~200 of FMA chain).  NGR = rank groups actually applied (ranks >= kk are exact
+           * no-ops: skipped). */
+          auto rows_of_block = [&](auto ngc) QP_ALWAYS_INLINE {
+            /* Two columns at a time, skewed by one rank: while stream A applies rank r of column c, stream B applies rank
+             * r - 1 of column c + 1 (which needs w_{r-1} after A's rank r - 1: done one step earlier).  The two streams
+             * are independent chains, so the wavefront always has an instruction ready when its dependent one is still in
+             * the pipe: sharing its SIMD with other wavefronts (which take every issue slot it leaves open, priority or
+             * not) it advances a rank of BOTH columns in the time the single chain needed for one (measured on MI355X:
+             * ~500 clk per column for the single chain of 32 FMAs even with no other workgroup on the CU).  Every entry
+             * still gets the same FMAs in the same order.  The pairs rotate through four register slots per stream. */
+            constexpr int KE = 8 * decltype(ngc)::value; /* ranks actually applied */
+            constexpr int D = 4;
+            double cfA[D][2], cfB[D][2];
 #pragma unroll
-            for (int u = 0; u < QD; u++) {
-              const int c1 = c0 + u;
-              double l = q[u];
-              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
-#pragma unroll
-              for (int rb = 0; rb < K; rb += 8) {
-                if (rb >= kk) break; /* ranks >= kk are exact no-ops (w = 0, gamma = 0): skipped, wave-uniform */
-                double cw[8], cg[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                  if (rb + r < K) {
-                    wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
-                    l = QP_FMA(cg[r], wrow[rb + r], l);
-                  }
-                }
-              }
-              rowp[(size_t)c1 * cstride] = l;
-              if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
-              QP_SCHED_BARRIER();
-              q[u] = rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
-              QP_SCHED_BARRIER();
+            for (int r = 0; r < D; r++) {
+              cfA[r][0] = U.cwg[prv][0][r][0]; cfA[r][1] = U.cwg[prv][0][r][1];
+              cfB[r][0] = U.cwg[prv][1][r][0]; cfB[r][1] = U.cwg[prv][1][r][1];
             }
-          };
-          /* first group peeled: the loop is then entered with as many memory operations in flight as
-           * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
-          group(0);
+            auto group = [&](const int c0) QP_ALWAYS_INLINE {
+#pragma unroll
+              for (int u = 0; u < QD; u += 2) {
+                const int cA = c0 + u, cB = cA + 1;
+                const int cAn = (cA + 2 < NB) ? cA + 2 : NB - 2, cBn = cAn + 1; /* past the last pair: re-reads it (unused) */
+                double lA = q[u], lB = q[u + 1];
+#pragma unroll
+                for (int r = 0; r <= KE; r++) {
+                  const int ra = r & (K - 1), rb = (r - 1) & (K - 1);
+                  if (r < KE) wrow[ra] = QP_FMA(cfA[r % D][0], lA, wrow[ra]);
+                  if (r >= 1) wrow[rb] = QP_FMA(cfB[(r - 1) % D][0], lB, wrow[rb]);
+                  if (r < KE) lA = QP_FMA(cfA[r % D][1], wrow[ra], lA);
+                  if (r >= 1) lB = QP_FMA(cfB[(r - 1) % D][1], wrow[rb], lB);
+                  QP_SCHED_BARRIER();
+                  if (r < KE) {
+                    const int rn = (r + D < KE) ? r + D : r + D - KE, cn = (r + D < KE) ? cA : cAn;
+                    cfA[r % D][0] = U.cwg[prv][cn][rn][0]; cfA[r % D][1] = U.cwg[prv][cn][rn][1];
+                  }
+                  if (r >= 1) {
+                    const int rn = (r - 1 + D < KE) ? r - 1 + D : r - 1 + D - KE, cn = (r - 1 + D < KE) ? cB : cBn;
+                    cfB[(r - 1) % D][0] = U.cwg[prv][cn][rn][0]; cfB[(r - 1) % D][1] = U.cwg[prv][cn][rn][1];
+                  }
+                  QP_SCHED_BARRIER();
+                }
+                rowp[(size_t)cA * cstride] = lA;
+                rowp[(size_t)cB * cstride] = lB;
+                if (fuse) { /* columns Jp + cA, Jp + cB are final for this row */
+                  accp = QP_FMA(-lA, U.ys[prv][cA], accp);
+                  accp = QP_FMA(-lB, U.ys[prv][cB], accp);
+                }
+                QP_SCHED_BARRIER();
+                { /* refill AFTER the slots' registers are free: no queue rotation on the back edge */
+                  const int cpa = (cA + QD < NB) ? cA + QD : NB - 2, cpb = cpa + 1;
+                  q[u] = QP_USQ ? U.Lsq[cur][cpa][lrow] : rowp[(size_t)cpa * cstride];
+                  q[u + 1] = QP_USQ ? U.Lsq[cur][cpb][lrow] : rowp[(size_t)cpb * cstride];
+                }
+                QP_SCHED_BARRIER();
+              }
+            };
+            /* first group peeled: the loop is then entered with as many memory operations in flight as
+             * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
+            group(0);
 #pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+            for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+          };
+          if constexpr (K > 8) {
+            if (kk > 8) rows_of_block(std::integral_constant<int, 2>{});
+            else rows_of_block(std::integral_constant<int, 1>{});
+          } else rows_of_block(std::integral_constant<int, 1>{});
         }
+        if (QP_PANEL_TIMING && lane == 0) tdbg[8] += QP_CLOCK() - tp0;
+        const long long tp1 = QP_CLOCK();
         double dreg = (lane < jb) ? U.dd[cur][lane] : 1.0;          /* lane c holds the pivot of column c */
         double lnext = (lane > 0 && lane < jb) ? U.Ld[cur][lane][0] : 0.0;
         /* Rolled on purpose: unrolled, the 32 lane masks and lane-derived LDS addresses become
@@ -1092,41 +1150,58 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
           {
             double l = lcur;
+            double cf[8][2]; /* same register rotation as above, within the column (the next column's pairs do not exist yet) */
 #pragma unroll
-            for (int rb = 0; rb < K; rb += 8) {
-              if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
-              double cw[8], cg[8];
-#pragma unroll
-              for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][1] : 0.0; }
+            for (int r = 0; r < 8; r++) { cf[r][0] = U.cwg[cur][c1][r][0]; cf[r][1] = U.cwg[cur][c1][r][1]; }
+            if (K > 8 && kk > 8) { /* ranks >= kk: exact no-ops, skipped */
 #pragma unroll
               for (int r = 0; r < 8; r++) {
-                if (rb + r < K) {
-                  wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
-                  l = QP_FMA(cg[r], wrow[rb + r], l);
-                }
+                wrow[r] = QP_FMA(cf[r][0], l, wrow[r]);
+                l = QP_FMA(cf[r][1], wrow[r], l);
+                QP_SCHED_BARRIER();
+                cf[r][0] = U.cwg[cur][c1][(8 + r) & (K - 1)][0]; cf[r][1] = U.cwg[cur][c1][(8 + r) & (K - 1)][1];
+                QP_SCHED_BARRIER();
+              }
+#pragma unroll
+              for (int r = 0; r < 8; r++) {
+                wrow[(8 + r) & (K - 1)] = QP_FMA(cf[r][0], l, wrow[(8 + r) & (K - 1)]);
+                l = QP_FMA(cf[r][1], wrow[(8 + r) & (K - 1)], l);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; r++) {
+                wrow[r] = QP_FMA(cf[r][0], l, wrow[r]);
+                l = QP_FMA(cf[r][1], wrow[r], l);
               }
             }
             if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;
           }
           QP_SCHED_BARRIER();
         }
+        if (QP_PANEL_TIMING && lane == 0) tdbg[9] += QP_CLOCK() - tp1;
 #endif
+        const long long tp2 = QP_CLOCK();
         if (fuse) { /* the diagonal block is final: y_J = L_JJ^{-1} (b_J - contributions of the earlier blocks) */
           double v = accp;
+          double lc = (lane > 0 && lane < jb) ? U.Ld[cur][lane][0] : 0.0;
 #pragma unroll 1
           for (int c = 0; c < jb; c++) {
             const int ln = QP_FRESH_LANE(lane);
+            const double lcn = (ln > c + 1 && ln < jb) ? U.Ld[cur][ln][c + 1] : 0.0; /* in flight during this step (column NB is padding) */
             const double yc = qp_readlane(v, c);
-            const double lc = (ln > c && ln < jb) ? U.Ld[cur][ln][c] : 0.0;
             v = QP_FMA(-lc, yc, v);
+            lc = lcn;
           }
           if (lane < jb) { U.ys[cur][lane] = v; fs[J + lane] = v; }
+          if (QP_UHELP) { QP_WAVE_SYNC(); if (lane == 0) QP_FLAG_STORE(&U.prog[cur], NB + 1); } /* y of block s is published */
         }
         /* diagonal block and pivots back to HBM (each lane re-reads what it wrote itself) */
         if (lane < jb) Dg[J + lane] = dreg;
+        if (!QP_USQ) {
 #pragma unroll 1
-        for (int c = 0; c < jb; c++)
-          if (lane > c && lane < jb) L[(size_t)(J + c) * ld + (J + lane)] = U.Ld[cur][lane][c];
+          for (int c = 0; c < jb; c++)
+            if (lane > c && lane < jb) L[(size_t)(J + c) * ld + (J + lane)] = U.Ld[cur][lane][c];
+        }
         /* back to being an ordinary owner: the running w of this wavefront's own rows */
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
@@ -1136,6 +1211,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live0 ? U.stash_acc[rr][lane] : 0.0;
         QP_SETPRIO(0);
         if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
+        if (QP_PANEL_TIMING && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
+        tpe = QP_CLOCK();
       }
       if (wid != 0 || own_live0) {
         /* ===== owners: table s-1 on the rows below block s ======================================= */
@@ -1221,21 +1298,39 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         }
         if (tid == QP_T - 64) tdbg[2] += QP_CLOCK() - tt0; /* the last wavefront's rows live longest */
       }
-      if (wid != 0 || QP_NW == 1) { /* diagonal block s+1 for the next phase */
-        const int t0 = (QP_NW == 1) ? tid : tid - 64, nt = (QP_NW == 1) ? QP_T : QP_T - 64;
-        for (int e = t0; e < jbn * jbn; e += nt) {
-          const int c1 = e / jbn, c = e % jbn;
-          if (c > c1) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
+      constexpr int NFREE = (QP_NW == 1) ? 0 : ((QP_UHELP && QP_NW >= 3) ? 2 : 1); /* wavefronts with a job of their own in this phase */
+      if (wid >= NFREE) { /* diagonal block s+1 for the next phase */
+        const int t0 = tid - 64 * NFREE, nt = QP_T - 64 * NFREE;
+        if (QP_USQ) {
+          /* buffer [prv] still holds diagonal block s-1 as the panel wave left it in the last phase: back to HBM, then
+           * block s+1 in its place (element by element, same thread); the square under block s goes to Lsq[prv] */
+          for (int e = t0; e < NB * NB; e += nt) {
+            const int c1 = e / NB, c = e % NB;
+            if (c > c1) {
+              if (s > 0) L[(size_t)(Jp + c1) * ld + (Jp + c)] = U.Ld[prv][c][c1];
+              if (c < jbn) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
+            }
+            if (!QP_UHELP && jbn > 0) U.Lsq[prv][c1][c] = (c < jbn) ? L[(size_t)(J + c1) * ld + (Jn + c)] : 0.0;
+          }
+        } else {
+          for (int e = t0; e < jbn * jbn; e += nt) {
+            const int c1 = e / jbn, c = e % jbn;
+            if (c > c1) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
+          }
         }
         if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
       }
       if (QP_UHELP && wid == 1 && jbn > 0) {
-        /* ===== helper wave: the 32 rows of block s+1 (lane = row, handed over in phase s-1 with
-         * tables < s-1 applied) get table s-1 and then table s, column by column right behind the
-         * panel wave (LDS column counter, no barrier): ready when the phase ends. ================ */
+        /* ===== helper wave: the 32 rows of block s+1 (lane = row, handed over in phase s-1 with the tables < s-1 applied)
+         * get table s-1 (complete) and then table s, pair of columns by pair of columns right behind the panel wave (LDS
+         * column counter, no barrier): the rows are ready for the recurrence of block s+1 when the phase ends, and the
+         * panel wave -- the serial chain of the sweep, bound by its instruction count -- never applies a table itself.
+         * Fused forward substitution: the terms of the columns of block s need y of block s, which the panel wave only
+         * has at the end of the phase; the final l of those columns are parked in LDS (Lsq[0]) and the 32 terms are added,
+         * in column order like everywhere else, once the panel wave signals that ys is there. ================ */
         const long long th0 = QP_CLOCK();
         if (lane == 0) tdbg[14] += th0 - tph0; /* helper start delay */
-        QP_SETPRIO(3);
+        QP_SETPRIO(2);
         /* this wavefront's own running w leaves the registers for the duration (HBM/L2 stash; the LDS
          * stash belongs to wavefront 0), only while its own rows are still live */
         const bool own_live1 = (64 * RPT * 2 - 1 >= Jo);
@@ -1245,65 +1340,120 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
             for (int r = 0; r < K; r++) hst[(rr * K + r) * 64 + lane] = w[rr][r];
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) hst[(RPT * K + rr) * 64 + lane] = acc[rr];
         }
         const int hs = (s + 1) % 3;
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jbn) ? U.Wd[hs][lane][r] : 0.0;
+        double hacc = (lane < jbn) ? U.Wd[hs][lane][K] : 0.0;
+        const int lrow = lane & (NB - 1);
         constexpr int QD = 8;
         const size_t cstride = (lane < jbn) ? (size_t)ld : 0;
-#pragma unroll 1
-        for (int pass = (s > 0) ? 0 : 1; pass < 2; pass++) { /* 0: table s-1 (complete), 1: table s (growing) */
+        /* one table applied to the rows: two columns at a time, skewed by one rank (two independent FMA chains), the
+         * (-w_j, -gamma) pairs rotating through four register slots per chain -- see rows_of_block above */
+        auto apply_table = [&](auto kec, auto passc) QP_ALWAYS_INLINE {
+          constexpr int KE = decltype(kec)::value; /* ranks actually applied (ranks >= kk are exact no-ops) */
+          constexpr int pass = decltype(passc)::value; /* 0: table s-1 (complete), 1: table s (growing) */
+          constexpr int D = 4;
           const int tb = pass ? cur : prv;
           qp_gdouble *rowp = (lane < jbn) ? (L + (size_t)(pass ? J : Jp) * ld + Jn + lane) : (dummy + lane);
           double q[QD];
 #pragma unroll
           for (int cc = 0; cc < QD; cc++) q[cc] = rowp[(size_t)cc * cstride];
           int avail = pass ? 0 : NB; /* columns of the table known to be published */
-          auto group = [&](const int c0) QP_ALWAYS_INLINE {
+          double cfA[D][2], cfB[D][2];
+          auto group = [&](const int c0, const bool first) QP_ALWAYS_INLINE {
 #pragma unroll
-            for (int u = 0; u < QD; u++) {
-              const int c1 = c0 + u;
-              while (avail <= c1) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= c1) QP_SPIN_PAUSE(); }
-              double l = q[u];
-              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+            for (int u = 0; u < QD; u += 2) {
+              const int cA = c0 + u, cB = cA + 1;
+              const int cAn = (cA + 2 < NB) ? cA + 2 : NB - 2, cBn = cAn + 1;
+              while (avail <= cB) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= cB) QP_SPIN_PAUSE(); }
+              if (pass || (first && u == 0)) {
+                /* growing table: the next pair of columns cannot be read ahead, the slots are filled per pair */
 #pragma unroll
-              for (int rb = 0; rb < K; rb += 8) {
-                if (rb >= kk) break;
-                double cw[8], cg[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[tb][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[tb][c1][rb + r][1] : 0.0; }
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                  if (rb + r < K) {
-                    wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
-                    l = QP_FMA(cg[r], wrow[rb + r], l);
-                  }
+                for (int r = 0; r < D; r++) {
+                  cfA[r][0] = U.cwg[tb][cA][r][0]; cfA[r][1] = U.cwg[tb][cA][r][1];
+                  cfB[r][0] = U.cwg[tb][cB][r][0]; cfB[r][1] = U.cwg[tb][cB][r][1];
                 }
               }
-              rowp[(size_t)c1 * cstride] = l;
+              double lA = q[u], lB = q[u + 1];
+#pragma unroll
+              for (int r = 0; r <= KE; r++) {
+                const int ra = r & (K - 1), rb = (r - 1) & (K - 1);
+                if (r < KE) wrow[ra] = QP_FMA(cfA[r % D][0], lA, wrow[ra]);
+                if (r >= 1) wrow[rb] = QP_FMA(cfB[(r - 1) % D][0], lB, wrow[rb]);
+                if (r < KE) lA = QP_FMA(cfA[r % D][1], wrow[ra], lA);
+                if (r >= 1) lB = QP_FMA(cfB[(r - 1) % D][1], wrow[rb], lB);
+                QP_SCHED_BARRIER();
+                if (r < KE && (r + D < KE || !pass)) {
+                  const int rn = (r + D < KE) ? r + D : r + D - KE, cn = (r + D < KE) ? cA : cAn;
+                  cfA[r % D][0] = U.cwg[tb][cn][rn][0]; cfA[r % D][1] = U.cwg[tb][cn][rn][1];
+                }
+                if (r >= 1 && (r - 1 + D < KE || !pass)) {
+                  const int rn = (r - 1 + D < KE) ? r - 1 + D : r - 1 + D - KE, cn = (r - 1 + D < KE) ? cB : cBn;
+                  cfB[(r - 1) % D][0] = U.cwg[tb][cn][rn][0]; cfB[(r - 1) % D][1] = U.cwg[tb][cn][rn][1];
+                }
+                QP_SCHED_BARRIER();
+              }
+              rowp[(size_t)cA * cstride] = lA;
+              rowp[(size_t)cB * cstride] = lB;
+              if (fuse) {
+                if (pass) { if (lane < NB) { U.Lsq[0][cA][lane] = lA; U.Lsq[0][cB][lane] = lB; } } /* y of block s comes at the end of the phase */
+                else { hacc = QP_FMA(-lA, U.ys[prv][cA], hacc); hacc = QP_FMA(-lB, U.ys[prv][cB], hacc); }
+              }
               QP_SCHED_BARRIER();
-              q[u] = rowp[(size_t)cpre * cstride];
+              {
+                const int cpa = (cA + QD < NB) ? cA + QD : NB - 2, cpb = cpa + 1;
+                q[u] = rowp[(size_t)cpa * cstride];
+                q[u + 1] = rowp[(size_t)cpb * cstride];
+              }
               QP_SCHED_BARRIER();
             }
           };
-          group(0);
+          group(0, true);
 #pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0, false);
+        };
+        typedef std::integral_constant<int, 0> P0;
+        typedef std::integral_constant<int, 1> P1;
+        typedef std::integral_constant<int, 8> K8;
+        typedef std::integral_constant<int, 16> K16;
+        if constexpr (K > 8) {
+          if (kk > 8) { if (s > 0) apply_table(K16{}, P0{}); apply_table(K16{}, P1{}); }
+          else { if (s > 0) apply_table(K8{}, P0{}); apply_table(K8{}, P1{}); }
+        } else { if (s > 0) apply_table(K8{}, P0{}); apply_table(K8{}, P1{}); }
+        if (fuse) { /* the terms of the columns of block s, once the panel wave has published y of block s */
+          int avail = 0;
+          while (avail <= NB) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= NB) QP_SPIN_PAUSE(); }
+#pragma unroll 8
+          for (int c = 0; c < NB; c++) hacc = QP_FMA(-U.Lsq[0][c][lrow], U.ys[cur][c], hacc);
         }
         if (lane < jbn) {
 #pragma unroll
           for (int r = 0; r < K; r++) U.Wd[hs][lane][r] = wrow[r];
+          U.Wd[hs][lane][K] = hacc;
         }
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
 #pragma unroll
           for (int r = 0; r < K; r++) w[rr][r] = own_live1 ? hst[(rr * K + r) * 64 + lane] : 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live1 ? hst[(RPT * K + rr) * 64 + lane] : 0.0;
         QP_SETPRIO(0);
         QP_WAVE_SYNC(); /* every lane is past its flag reads before the counter is re-armed */
         if (lane == 0) { U.prog[cur] = 0; tdbg[13] += QP_CLOCK() - th0; }
       }
       __syncthreads();
+      if (QP_PANEL_TIMING && tid == 0) tdbg[11] += QP_CLOCK() - tpe;
+    }
+    if (QP_USQ) { /* the last diagonal block is still in LDS */
+      const int sl = nblk - 1, Jl = J0 + sl * NB, jbl = n - Jl;
+      for (int e = tid; e < NB * NB; e += QP_T) {
+        const int c1 = e / NB, c = e % NB;
+        if (c > c1 && c < jbl) L[(size_t)(Jl + c1) * ld + (Jl + c)] = U.Ld[sl & 1][c][c1];
+      }
     }
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[7] += tq1 - tq0; tq0 = tq1; }
   }

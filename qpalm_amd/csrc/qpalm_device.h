@@ -25,6 +25,11 @@
 #define QP_T 512
 #endif
 #define QP_NW (QP_T / 64)
+/* ranks per update sweep by rows-per-thread: the running vectors w[RPT][K] must fit the 128-VGPR budget; the 256-thread
+ * instance (small QPs, four workgroups per CU) always uses 8 (its 40 KB LDS share bounds the coefficient tables) */
+#ifndef QP_KSEL
+#define QP_KSEL(RPT) ((RPT) <= 2 ? 16 : 8)
+#endif
 #define QPD __device__ __forceinline__
 #define QPN __device__ __forceinline__
 /* a real call: the callee gets its own register allocation instead of inheriting the live values of
@@ -63,6 +68,9 @@ typedef emu_double4 qp_double4;
 #define QP_OPAQUE_V(x) do { } while (0)
 #define QP_FRESH_LANE(lane) (lane)
 #define QP_ALWAYS_INLINE
+/* emulation: one "CU", wavefront w sits on "SIMD" w & 3 (exercises the panel-wave rotation) */
+#define QP_HW_CU_KEY() 0
+#define QP_HW_SIMD() ((int)(threadIdx.x >> 6) & 3)
 #else
 typedef double qp_double4 __attribute__((ext_vector_type(4)));
 #define QP_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -95,6 +103,10 @@ static __device__ __forceinline__ int qp_fresh_lane_() {
 }
 #define QP_FRESH_LANE(lane) qp_fresh_lane_()
 #define QP_ALWAYS_INLINE __attribute__((always_inline))
+/* where this wavefront runs: HW_REG_HW_ID (id 4: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and
+ * HW_REG_XCC_ID (id 20, bits 3:0) -- s_getreg_b32 with (size-1) << 11 | offset << 6 | id */
+#define QP_HW_SIMD() ((int)__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4))
+#define QP_HW_CU_KEY() ((int)(__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 8)))
 #endif
 
 /* ---- c_max / c_min / c_absval exactly as the reference's macros (include/global_opts.h) ---- */
@@ -111,6 +123,9 @@ struct QpShared {          /* small static LDS block */
   double bc[QP_NRED];      /* broadcast scalars */
   int    ired[QP_NW][4];
   int    ibc[8];
+  int    hw_simd[QP_NW];   /* SIMD each wavefront of this workgroup sits on */
+  int    placement;        /* diagnostic code of the placement (QPGStats.placement) */
+  int    panel_wave;       /* the wavefront that runs the serial chains of the update sweep (qp_place_panel_wave) */
 };
 
 QPD double wave_sum(double v) {

@@ -6,8 +6,51 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <type_traits>
 
+#include "qpalm_types.h"
+
+/* The kernels are instantiated twice (same source, different workgroup size):
+ *   qp512: 512 threads = 8 wavefronts per QP, two workgroups per CU (64 KB dynamic LDS each) -- the general instance;
+ *   qp256: 256 threads = 4 wavefronts per QP, FOUR workgroups per CU (38 KB dynamic LDS each) -- for small QPs (factor of
+ *          at most 256 rows, e.g. the mpc-160 workload): their phases are bound by dependent-load latency, not by work
+ *          per QP, so the lever is more QPs in flight per CU (measured: DESIGN.md section 7). */
+#define QP_T 512
+#define QP_KSEL(RPT) ((RPT) <= 2 ? 16 : 8)
+#define QP_FKC 32
+#define QP_USQ 1
+#ifndef QP_UHELP_512
+#define QP_UHELP_512 0
+#endif
+#define QP_UHELP QP_UHELP_512
+namespace qp512 {
 #include "qpalm_kernels.h"
+}
+#undef QP_T
+#undef QP_KSEL
+#undef QP_FKC
+#undef QP_USQ
+#undef QP_UHELP
+#undef QPALM_KERNELS_H
+#undef QPALM_DEVICE_H
+#undef QPALM_DENSE_H
+#undef QPALM_ITER_H
+#undef QPALM_KKT_H
+#define QP_T 256
+#define QP_KSEL(RPT) 8
+#define QP_FKC 16
+#define QP_USQ 0
+#define QP_UHELP 0
+namespace qp256 {
+#include "qpalm_kernels.h"
+static_assert(sizeof(UpdownLds<1, 8>) <= 38912 && sizeof(FactorLds) + sizeof(FactorStage) + 64 <= 38912 && sizeof(SolveLds) + 8 * 256 <= 38912,
+              "the 256-thread instance runs with 38 KB of dynamic LDS");
+}
+#undef QP_T
+#define QP_T 512 /* the general instance's workgroup size (limits quoted by the host code) */
+#define QP_T_SMALL 256
+#define QP_LDS_SMALL 38912
+#define QP_TWO_INSTANCES 1
 
 static std::string g_rt_err;
 static int g_rt_sticky = 0; /* a failed copy/memset is remembered until the API call returns (api_ok() in qpalm_capi.inc) */

@@ -10,6 +10,9 @@
  */
 #ifndef QPALM_ITER_H
 #define QPALM_ITER_H
+#ifndef QP_NOFUSE
+#define QP_NOFUSE 0 /* 1 (experiments): the Newton solve does not ride on the last update sweep */
+#endif
 
 #define QP_KIND_NEWTON 0
 #define QP_KIND_OUTER 1
@@ -254,7 +257,7 @@ QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, doub
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
   if constexpr (RPT == 0) dense_updown_big<16>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin);
-  else dense_updown<RPT, (RPT <= 2 ? 16 : 8)>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin, fs);
+  else dense_updown<RPT, QP_KSEL(RPT)>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin, fs);
 }
 
 /* =============================================================================================
@@ -614,6 +617,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
       for (int k = 0; k < QPG_NDBG; k++) I.s.ticks_dbg[k] = 0;
+      I.s.ticks_dbg[QPG_CNT_PLACEMENT] = I.S.placement;
     }
     __syncthreads();
   }
@@ -859,7 +863,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
       const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
       /* a Newton step solves right after the update: its forward substitution rides on the last sweep */
       double *fs = nullptr;
-      constexpr bool FUSED = (RPT > 0); /* the large-factor sweep keeps the solve separate */
+      constexpr bool FUSED = (RPT > 0) && !QP_NOFUSE; /* the large-factor sweep keeps the solve separate */
       if (FUSED && la == 2) {
         for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1; /* ldlsolveLD_neg_dphi's right-hand side */
         fs = a.d();
@@ -876,7 +880,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
       if (!V.kkt) {
-        const bool fused = (RPT > 0) && (action == 2);
+        const bool fused = (RPT > 0) && !QP_NOFUSE && (action == 2);
         if (!fused) for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
         __syncthreads();
         dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg, fused ? 2 : 0); /* 2: d already holds L^{-1} (-dphi) */

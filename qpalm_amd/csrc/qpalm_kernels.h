@@ -244,12 +244,37 @@ __global__ __launch_bounds__(QP_T) void k_warm_start(qpg_view V, int has_x, int 
   }
 }
 
+/* Which wavefront of this workgroup runs the serial chains of the update sweep.  The workgroups that share a compute
+ * unit stay there for the whole launch (persistent kernel), and the hardware starts every workgroup's wavefront 0 on the
+ * same SIMD: with "wavefront 0" as the panel wave of both, the two serial chains of a CU would take turns on one SIMD's
+ * issue port while the other SIMDs wait for their tables.  So the k-th workgroup to arrive on a CU (atomic counter per
+ * (XCC, SE, SH, CU) id, zeroed by the host before the launch) picks a wavefront by the SIMD it sits on. */
+QPD void qp_place_panel_wave(const qpg_view &V, QpShared &S) {
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) S.hw_simd[wid] = QP_HW_SIMD();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int key = QP_HW_CU_KEY() & (QPG_CU_KEYS - 1);
+    const int arrival = atomicAdd(V.queue + 64 + key, 1);
+    int pw = 0;
+    /* eight wavefronts per workgroup = two workgroups per CU: panel waves on SIMDs 0 and 2, so that the wavefront after
+     * the panel wave (the helper wave of the update sweep, second in priority) does not share a SIMD with the other
+     * workgroup's panel wave either */
+    const int target = (QP_NW >= 8) ? 2 * (arrival & 1) : (arrival & 3);
+    for (int w = QP_NW - 1; w >= 0; w--) if (S.hw_simd[w] == target) pw = w;
+    S.panel_wave = V.place_panel_wave ? pw : 0;
+    S.placement = key << 16 | (arrival & 255) << 8 | S.panel_wave << 4 | S.hw_simd[0];
+  }
+  __syncthreads();
+}
+
 /* The persistent solver: workgroup `blockIdx.x` owns factor slot `blockIdx.x` and pulls QPs either
  * statically (b = blockIdx.x, resumable, needs B <= grid) or from an atomic work queue. */
 template <int RPT>
 __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_solve(qpg_view V, int budget, int dynamic) {
   __shared__ IterShared I;
   char *lds = QP_DYN_LDS();
+  qp_place_panel_wave(V, I.S);
   /* one call site of dev_solve (= one copy of the iteration loop in the kernel): static round-robin
    * or the atomic work queue only differ in how the next QP index is obtained */
   int b = blockIdx.x - gridDim.x;
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
   const QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x, slot = b;
   double *L = V.L + (size_t)slot * V.ld * V.nfac, *Dg = V.Dg + (size_t)slot * V.nfac, *Wst = V.Wst + (size_t)slot * V.wst_stride;
-  if (tid == 0) I.s = V.sc[b];
+  if (tid == 0) { I.s = V.sc[b]; I.S.panel_wave = 0; I.S.placement = 0; }
   __syncthreads();
   switch (op) {
     case QP_OP_MATVEC_A: spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;

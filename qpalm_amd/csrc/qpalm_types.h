@@ -35,11 +35,15 @@ typedef struct {
   double max_rank_update_fraction;
 } qpg_settings;
 
+#define QPG_CU_KEYS 4096 /* 16 XCC ids x 256 (se, sh, cu) ids of HW_REG_HW_ID */
 #define QPG_NDBG 20
 #define QPG_CNT_SWEEP_ENTRIES 16 /* entries of L (doubles) the rank-update sweeps read AND wrote: sum of nnz(L[:, J0:]) */
 #define QPG_CNT_SWEEPS 17        /* sweeps over the panel (<= K ranks each, K = 16 or 8 by instantiation) */
 #define QPG_CNT_FACTOR_REREAD 18 /* entries of L re-read by the left-looking panel updates of the factorisation */
-#define QPG_CNT_SPARE 19
+#define QPG_CNT_PLACEMENT 19     /* not a counter: where the workgroup ran (QPGStats.placement) */
+/* dynamic LDS of a 512-thread workgroup: the update sweep's scratch (UpdownLds<2, 16>: 77 192 bytes); two workgroups plus
+ * their static LDS fit the 160 KB of a CU */
+#define QPG_LDS_DEFAULT 77824
 
 /* per-QP scalar state: everything qpalm_solve keeps in locals or in QPALMWorkspace scalars
  * (src/qpalm.c:401-482, include/types.h:197-314), so that a solve can be suspended after any
@@ -70,7 +74,7 @@ typedef struct {
 
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
-  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride;
+  int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, place_panel_wave;
   int32_t kkt, nfac; /* kkt != 0: FACTORIZE_KKT, the factor slots hold the (n+m) x (n+m) KKT panel; nfac = rows of a factor slot
                         (n, or n + m in KKT mode); ld = its leading dimension */
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.
@@ -103,7 +107,7 @@ typedef struct {
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */
-  int32_t *queue; /* [4] work-queue head etc. */
+  int32_t *queue; /* [64 + QPG_CU_KEYS]: [0] work-queue head; [64 + key] workgroups that have arrived on compute unit `key` in this launch */
 } qpg_view;
 
 #define QPG_KMAX 16

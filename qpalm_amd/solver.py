@@ -110,6 +110,12 @@ class QpalmBatch:
         self._check(self.L.qpg_batch_last_solve_ms(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def launch_shape(self):
+        """(concurrent workgroups, threads per workgroup, LDS bytes per workgroup) of this batch."""
+        w, t, l = capi.c_int(0), capi.c_int(0), capi.c_int(0)
+        self._check(self.L.qpg_batch_launch_shape(self.h, C.byref(w), C.byref(t), C.byref(l)))
+        return int(w.value), int(t.value), int(l.value)
+
     def num_unfinished(self):
         c = capi.c_int(0)
         self._check(self.L.qpg_batch_num_unfinished(self.h, C.byref(c)))

@@ -520,6 +520,27 @@ def test_refactor_policy_changes_speed_not_results(ctx):
     _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0), rank_thr=2)
 
 
+def test_workgroup_shapes_and_placement_do_not_change_results(ctx):
+    """QPs whose factor has at most 256 rows run on 256-thread workgroups (four per CU) by default; the 512-thread
+    instance, and every workgroup running its serial chains on wavefront 0, must give the same answers (all against
+    the oracle, and the launch shape is what the library reports)."""
+    n, m = sizes(ctx, (40, 80), (160, 270))
+    probs = [random_qp(n, m, seed=5100 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(sizes(ctx, 2, 6))]
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    try:
+        for small, place in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            ctx.set_option("small_workgroups", small)
+            ctx.set_option("place_panel_wave", place)
+            bt = _compare_solve(ctx, probs, st)
+            wgs, threads, lds = bt.launch_shape()
+            assert wgs >= 1 and lds >= 32 * 1024
+            if ctx.kind == "hip":
+                assert threads == (256 if small else 512)
+    finally:
+        ctx.set_option("small_workgroups", 1)
+        ctx.set_option("place_panel_wave", 1)
+
+
 def test_mpc_qps_match_oracle(ctx):
     T = sizes(ctx, 3, 10)
     probs = [random_mpc_qp(T=T, nx=sizes(ctx, 4, 10), nu=sizes(ctx, 2, 5), seed=k) for k in range(2)]
