@@ -24,6 +24,7 @@
 /* LDS flags between wavefronts of one workgroup (helper wave of the update sweep) */
 #define QP_FLAG_STORE(p, v) (*(volatile int *)(p) = (v))
 #define QP_FLAG_LOAD(p) (*(volatile int *)(p))
+#define QP_FLAG_INC(p) ((*(volatile int *)(p))++)
 #define QP_SPIN_PAUSE() emu::yield_fiber()
 #else
 /* The flags and the data they guard both live in LDS, and the LDS unit executes the DS instructions
@@ -37,7 +38,11 @@ static __device__ __forceinline__ int qp_flag_load_(int __attribute__((address_s
   return v;
 }
 #define QP_FLAG_LOAD(p) qp_flag_load_((p))
-#define QP_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+#define QP_FLAG_INC(p) do { asm volatile("" ::: "memory"); (void)__hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); } while (0)
+#ifndef QP_SPIN_SLEEP
+#define QP_SPIN_SLEEP 1
+#endif
+#define QP_SPIN_PAUSE() __builtin_amdgcn_s_sleep(QP_SPIN_SLEEP)
 #define QP_SETPRIO(p) __builtin_amdgcn_s_setprio(p) /* issue priority of a wavefront on its SIMD */
 /* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
 #define QP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -721,7 +726,13 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
 #ifndef QP_UHELP
-#define QP_UHELP 0 /* 1: wavefront 1 applies the look-ahead rows column by column behind the panel wave */
+#define QP_UHELP 0 /* 1: wavefront 1 ("helper") applies table s to the rows of block s+1 column pair by column pair right behind
+                      the panel wave, so that the panel wave only runs the recurrence.  Parity-green (emulator and MI355X,
+                      with the fused solve), but measured SLOWER on MI355X in both forms tried in round 2: with the helper
+                      also applying table s-1 (64 columns per phase) it finishes ~13 us after the panel wave (its loads queue
+                      behind its own stores in vmcnt); with the owners applying table s-1 (this form) the panel wave's
+                      recurrence itself slows from 0.66 to 1.09 us per column while the helper runs next to it.  Update
+                      phase 80-92 ms per QP against 70 for the default.  Opt-in: -DQP_UHELP_512=1. */
 #endif
 #ifndef QP_PSPLIT
 #define QP_PSPLIT 0 /* 1: the panel wave splits the ranks of the block recurrence over its two half-waves (see dense_updown).
@@ -741,7 +752,7 @@ template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
   double Ld[2][QP_UNB][QP_UNB + 1];
   double Lsq[(QP_USQ && !QP_UHELP) ? 2 : 1][QP_USQ ? QP_UNB : 1][QP_UNB]; /* [parity][column of block s-1][row of block s]: the square under diagonal block s-1 */
-  double Wd[QP_UHELP ? 3 : 2][QP_UNB][K + 1]; /* running w of the rows of block b: owners -> (helper wave ->) panel wave */
+  double Wd[2][QP_UNB][K + 1]; /* running w of the rows of block b: owners -> (helper wave ->) panel wave */
   double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
@@ -749,7 +760,8 @@ struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block
   double dd[2][QP_UNB];
   double ys[2][QP_UNB];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
   double stash_acc[RPT][64];   /* ... and wavefront 0's own row accumulators while it is the panel wave */
-  int prog[2];                 /* helper variant: columns of table [parity] published so far */
+  int prog[2];                 /* helper variant: columns of table [parity] published so far (NB + 1: y of the block too) */
+  int hcnt[2];                 /* helper variant: rows of block [parity] handed over by their owners so far */
 };
 
 #ifdef QPALM_EMU
@@ -852,14 +864,13 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) {
         const int i = tid * RPT + rr;
-        if (i >= J0 && i < J0 + (QP_UHELP ? 2 * NB : jb0) && i < n) { /* block 0 (helper variant: blocks 0 and 1) */
-          const int bs = (i - J0) / NB;
+        if (i >= J0 && i < J0 + jb0) { /* block 0 */
 #pragma unroll
-          for (int r = 0; r < K; r++) U.Wd[bs][(i - J0) % NB][r] = w[rr][r];
-          U.Wd[bs][(i - J0) % NB][K] = acc[rr];
+          for (int r = 0; r < K; r++) U.Wd[0][i - J0][r] = w[rr][r];
+          U.Wd[0][i - J0][K] = acc[rr];
         }
       }
-      if (tid < 2) U.prog[tid] = 0;
+      if (tid < 2) { U.prog[tid] = 0; U.hcnt[tid] = 0; }
       if (tid < 2 * K) (&U.czero[0][0])[tid] = 0.0;
       for (int e = tid; e < jb0 * jb0; e += QP_T) {
         const int c1 = e / jb0, c = e % jb0;
@@ -886,9 +897,9 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       long long tpe = tph0;
       /* owners work on rows from Jo on and hand block Jo over: the block after this one, or (helper
        * variant) the one after that */
-      const int Jo = QP_UHELP ? Jn + NB : Jn;
+      const int Jo = Jn;
       const int jbo = (n - Jo < NB) ? ((n - Jo > 0) ? (n - Jo) : 0) : NB;
-      const int wslot = QP_UHELP ? (s % 3) : cur, hslot = QP_UHELP ? ((s + 2) % 3) : prv;
+      const int wslot = cur, hslot = prv;
       const bool own_live0 = (64 * RPT - 1 >= Jo); /* wavefront 0 still owns rows the owners work on */
       if (wid == 0) {
         /* ===== panel wave ===================================================================== */
@@ -1286,6 +1297,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
             for (int r = 0; r < K; r++) U.Wd[hslot][i - Jo][r] = w[rr][r];
             U.Wd[hslot][i - Jo][K] = acc[rr];
+            if (QP_UHELP) QP_FLAG_INC(&U.hcnt[prv]); /* after this lane's writes (LDS runs a wavefront's operations in order) */
           }
         }
         if (wid == 0) {
@@ -1321,8 +1333,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
       }
       if (QP_UHELP && wid == 1 && jbn > 0) {
-        /* ===== helper wave: the 32 rows of block s+1 (lane = row, handed over in phase s-1 with the tables < s-1 applied)
-         * get table s-1 (complete) and then table s, pair of columns by pair of columns right behind the panel wave (LDS
+        /* ===== helper wave: the 32 rows of block s+1 (lane = row, handed over by their owners in THIS phase as soon as
+         * these have applied table s-1) get table s, pair of columns by pair of columns right behind the panel wave (LDS
          * column counter, no barrier): the rows are ready for the recurrence of block s+1 when the phase ends, and the
          * panel wave -- the serial chain of the sweep, bound by its instruction count -- never applies a table itself.
          * Fused forward substitution: the terms of the columns of block s need y of block s, which the panel wave only
@@ -1343,7 +1355,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
           for (int rr = 0; rr < RPT; rr++) hst[(RPT * K + rr) * 64 + lane] = acc[rr];
         }
-        const int hs = (s + 1) % 3;
+        const int hs = prv;
+        { /* the owners of these rows hand them over when they are through with table s-1 */
+          int got = 0;
+          while (got < jbn) { got = QP_FLAG_LOAD(&U.hcnt[prv]); if (got < jbn) QP_SPIN_PAUSE(); }
+        }
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jbn) ? U.Wd[hs][lane][r] : 0.0;
@@ -1416,14 +1432,13 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll 1
           for (int c0 = QD; c0 < NB; c0 += QD) group(c0, false);
         };
-        typedef std::integral_constant<int, 0> P0;
         typedef std::integral_constant<int, 1> P1;
         typedef std::integral_constant<int, 8> K8;
         typedef std::integral_constant<int, 16> K16;
         if constexpr (K > 8) {
-          if (kk > 8) { if (s > 0) apply_table(K16{}, P0{}); apply_table(K16{}, P1{}); }
-          else { if (s > 0) apply_table(K8{}, P0{}); apply_table(K8{}, P1{}); }
-        } else { if (s > 0) apply_table(K8{}, P0{}); apply_table(K8{}, P1{}); }
+          if (kk > 8) apply_table(K16{}, P1{});
+          else apply_table(K8{}, P1{});
+        } else apply_table(K8{}, P1{});
         if (fuse) { /* the terms of the columns of block s, once the panel wave has published y of block s */
           int avail = 0;
           while (avail <= NB) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= NB) QP_SPIN_PAUSE(); }
@@ -1443,7 +1458,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live1 ? hst[(RPT * K + rr) * 64 + lane] : 0.0;
         QP_SETPRIO(0);
         QP_WAVE_SYNC(); /* every lane is past its flag reads before the counter is re-armed */
-        if (lane == 0) { U.prog[cur] = 0; tdbg[13] += QP_CLOCK() - th0; }
+        if (lane == 0) { U.prog[cur] = 0; U.hcnt[prv] = 0; tdbg[13] += QP_CLOCK() - th0; }
       }
       __syncthreads();
       if (QP_PANEL_TIMING && tid == 0) tdbg[11] += QP_CLOCK() - tpe;
