@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
+    ap.add_argument("--narrow-rows", type=int, default=1, help="0: Schur assembly with one wavefront per column also for small QPs (A/B)")
     ap.add_argument("--place-panel-wave", type=int, default=1, help="0: every workgroup runs its serial chains on wavefront 0 (A/B of the SIMD placement)")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
@@ -239,6 +240,8 @@ def worker(args):
         ctx.set_option("small_workgroups", 0)
     if not args.place_panel_wave:
         ctx.set_option("place_panel_wave", 0)
+    if not args.narrow_rows:
+        ctx.set_option("narrow_rows", 0)
     B = args.batch
     settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     rng = np.random.default_rng(12345 + rank)
@@ -292,7 +295,7 @@ def worker(args):
                 bmin_all[:, :10] = x0
                 bmax_all[:, :10] = x0
                 bt.update_bounds(bmin_all, bmax_all)
-                bt.warm_start(state["x"], state["y"])
+                bt.warm_start_last()      # previous solution, straight from HBM (== warm_start(*solution()), tests/test_mpc_scale.py)
             else:
                 bt.warm_start(None, None)
         else:

@@ -150,6 +150,7 @@ int  qpg_batch_set_problem_sized(qpg_batch *bt, qpg_int idx, qpg_int n, qpg_int 
                                  const qpg_float *q, qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
 int  qpg_batch_setup(qpg_batch *bt);                               /* upload + Ruiz scaling on device */
 int  qpg_batch_warm_start(qpg_batch *bt, const qpg_float *x, const qpg_float *y); /* [B][n], [B][m] or NULL */
+int  qpg_batch_warm_start_last(qpg_batch *bt);                     /* qpalm_warm_start(work, last x, last y) of every QP, from HBM (no host copy) */
 int  qpg_batch_solve(qpg_batch *bt);                               /* run every QP to termination */
 int  qpg_batch_iterate(qpg_batch *bt, qpg_int k);                  /* at most k more loop iterations each */
 int  qpg_batch_begin_solve(qpg_batch *bt);                         /* start of a qpalm_solve driven by qpg_batch_iterate: finished QPs start over */

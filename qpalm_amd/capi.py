@@ -80,7 +80,7 @@ def load(path=None):
     L.qpg_batch_create.argtypes = [C.c_void_p, c_int, c_int, c_int, c_int, c_int, C.POINTER(Settings), C.POINTER(C.c_void_p)]
     L.qpg_batch_set_problem.argtypes = [C.c_void_p, c_int, pi, pi, pf, pi, pi, pf, pf, c_float, pf, pf]
     L.qpg_batch_set_problem_sized.argtypes = [C.c_void_p, c_int, c_int, c_int, pi, pi, pf, pi, pi, pf, pf, c_float, pf, pf]
-    for f in ("qpg_batch_setup", "qpg_batch_solve", "qpg_batch_sync", "qpg_batch_begin_solve"):
+    for f in ("qpg_batch_setup", "qpg_batch_solve", "qpg_batch_sync", "qpg_batch_begin_solve", "qpg_batch_warm_start_last"):
         getattr(L, f).argtypes = [C.c_void_p]
     L.qpg_batch_warm_start.argtypes = [C.c_void_p, pf, pf]
     L.qpg_batch_iterate.argtypes = [C.c_void_p, c_int]
@@ -124,7 +124,7 @@ def load(path=None):
 SYMBOLS = [
     "qpg_last_error", "qpg_backend_name", "qpg_set_default_settings", "qpg_validate_settings", "qpg_ctx_create",
     "qpg_ctx_destroy", "qpg_ctx_set_option", "qpg_batch_create", "qpg_batch_set_problem", "qpg_batch_setup",
-    "qpg_batch_warm_start", "qpg_batch_solve", "qpg_batch_iterate", "qpg_batch_last_solve_ms", "qpg_batch_num_unfinished", "qpg_batch_launch_shape",
+    "qpg_batch_warm_start", "qpg_batch_warm_start_last", "qpg_batch_solve", "qpg_batch_iterate", "qpg_batch_last_solve_ms", "qpg_batch_num_unfinished", "qpg_batch_launch_shape",
     "qpg_batch_update_settings", "qpg_batch_update_bounds", "qpg_batch_update_q", "qpg_batch_get_info",
     "qpg_batch_get_stats", "qpg_batch_get_solution", "qpg_batch_get_vector", "qpg_batch_set_vector",
     "qpg_batch_get_ivector", "qpg_batch_set_ivector", "qpg_batch_set_scalar", "qpg_batch_get_factor",

@@ -78,6 +78,86 @@ QPD double qp_rcp(double x) {
 #endif
 
 /* ---------------------------------------------------------------------------------------------
+ * form_schur_narrow: the same assembly for SMALL QPs whose rows of A are short (MPC: ~7 entries): a quarter wavefront
+ * (16 lanes, one DPP row) per column, so that a workgroup assembles 4 QP_NW columns per round instead of QP_NW.  At this
+ * size the walk is a chain of ~7 dependent global round trips per column and nothing else, so the time goes with the
+ * number of rounds (measured on mpc-160, n = 160: 0.25 ms per assembly with one wavefront per column, 40 rounds).
+ * Same order of additions per entry as form_schur (active rows t ascending).
+ * ------------------------------------------------------------------------------------------- */
+QPN void form_schur_narrow(const qpg_view &V, int b, const int n, double *Lslot, bool with_AtSA, bool proximal, double gamma, char *lds) {
+  const int ld = V.ld;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, grp = lane >> 4, gl = lane & 15;
+  const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
+  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
+  const double *Atss = V.Atss + (size_t)b * V.nnzA;
+  const int *Ainv = V.Ainv + (size_t)b * V.nnzA;
+  const int *Qp = V.Qp + (size_t)b * (V.n + 1), *Qi = V.Qi + (size_t)b * V.nnzQ;
+  const double *Qx = V.Qx + (size_t)b * V.nnzQ;
+  const int *active = V.active + (size_t)b * V.m;
+  double *buf = (double *)lds + (size_t)(wid * 4 + grp) * n; /* one column buffer per quarter wavefront (host: 32 QP_NW n <= lds_bytes) */
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += 4 * QP_NW) {
+    const int j = j0 + wid * 4 + grp;
+    const bool colok = (j < n);
+    const int lo = colok ? j : 0;
+    if (colok) for (int i = j + gl; i < n; i += 16) buf[i] = 0.0;
+    QP_WAVE_SYNC();
+    if (with_AtSA) {
+      const int p0 = colok ? Ap[j] : 0, p1 = colok ? Ap[j + 1] : 0;
+      /* chunks of 16 entries of A(:,j): lane = entry; the wavefront runs as long as its longest column */
+      int more = 1;
+      for (int pb = p0; more; pb += 16) {
+        const int pidx = pb + gl;
+        const bool valid = pidx < p1;
+        const int t_l = valid ? Ai[pidx] : 0;
+        const int act_l = valid ? active[t_l] : 0;
+        int k0_l = 0, cnt_l = 0;
+        double vj_l = 0.0;
+        if (act_l) { k0_l = Atp[t_l]; cnt_l = Atp[t_l + 1] - k0_l; vj_l = Atss[Ainv[pidx]]; }
+        unsigned gmask = (unsigned)((__ballot(act_l) >> (16 * grp)) & 0xffffull); /* this column's active rows, ascending */
+        while (__ballot(gmask != 0)) {
+          /* two active rows per step (their entries of F are fetched together), added in ascending order */
+          int sl[2], cn[2], kk0[2], ig[2];
+          double vg[2], vjg[2];
+#pragma unroll
+          for (int g = 0; g < 2; g++) {
+            const bool has = gmask != 0;
+            sl[g] = has ? (__ffs((int)gmask) - 1) : 0;
+            if (has) gmask &= gmask - 1;
+            kk0[g] = __shfl(k0_l, 16 * grp + sl[g]); cn[g] = has ? __shfl(cnt_l, 16 * grp + sl[g]) : 0; vjg[g] = __shfl(vj_l, 16 * grp + sl[g]);
+            if (!has) cn[g] = 0;
+            ig[g] = 0; vg[g] = 0.0;
+            if (gl < cn[g]) { ig[g] = Ati[kk0[g] + gl]; vg[g] = Atss[kk0[g] + gl]; }
+          }
+#pragma unroll
+          for (int g = 0; g < 2; g++) {
+            if (gl < cn[g] && ig[g] >= lo) buf[ig[g]] += vg[g] * vjg[g];
+            for (int kb = 16; __ballot(kb < cn[g]); kb += 16) { /* rows of A with more than 16 entries */
+              const int k = kb + gl;
+              if (k < cn[g]) { const int i = Ati[kk0[g] + k]; if (i >= lo) buf[i] += Atss[kk0[g] + k] * vjg[g]; }
+            }
+            QP_WAVE_SYNC();
+          }
+        }
+        more = __ballot(pb + 16 < p1) != 0;
+      }
+    }
+    if (colok) {
+      for (int k = Qp[j] + gl; k < Qp[j + 1]; k += 16) {
+        const int i = Qi[k];
+        if (i >= j) buf[i] = Qx[k] + buf[i];
+      }
+    }
+    QP_WAVE_SYNC();
+    if (colok && proximal && gl == 0) buf[j] += 1.0 / gamma;
+    QP_WAVE_SYNC();
+    if (colok) for (int i = j + gl; i < n; i += 16) Lslot[(size_t)j * ld + i] = buf[i];
+    QP_WAVE_SYNC();
+  }
+  __syncthreads();
+}
+
+/* ---------------------------------------------------------------------------------------------
  * form_schur: H(:,j) for j = 0..n-1, lower triangle, written into the factor slot.
  *   H_ij = Q_ij + sum_{t active} F_it F_jt (+ 1/gamma on the diagonal), F = At_sqrt_sigma.
  * One wavefront assembles one column in an LDS column buffer: the active rows t of A(:,j) are
@@ -88,6 +168,7 @@ QPD double qp_rcp(double x) {
  * ------------------------------------------------------------------------------------------- */
 QPN double form_schur(const qpg_view &V, int b, const int n, double *Lslot, const bool GERSH, bool with_AtSA, bool proximal, double gamma,
                       QpShared &S, char *lds) {
+  if (!GERSH && V.narrow_rows) { form_schur_narrow(V, b, n, Lslot, with_AtSA, proximal, gamma, lds); return 0.0; }
   const int ld = V.ld; /* n = this QP's dimension; the per-QP strides below are the batch's V.n / V.m */
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;

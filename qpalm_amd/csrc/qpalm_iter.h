@@ -193,7 +193,7 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
   __syncthreads();
   if (has_x) {
     for (int j = tid; j < n; j += QP_T) {
-      double xv = a.x()[j];
+      double xv = (has_x == 2) ? a.sol_x()[j] : a.x()[j]; /* 2: this QP's last stored solution (qpg_batch_warm_start_last) */
       if (I.s.has_scaling) xv = xv * a.Dinv()[j];
       a.x()[j] = xv; a.x0()[j] = xv; a.x_prev()[j] = xv;
     }
@@ -215,7 +215,7 @@ QPN void dev_warm_start(const qpg_view &V, const QpArrays &a, int b, int has_x, 
   }
   if (has_y) {
     for (int i = tid; i < m; i += QP_T) {
-      double yv = a.y()[i];
+      double yv = (has_y == 2) ? a.sol_y()[i] : a.y()[i];
       if (I.s.has_scaling) { yv = yv * a.Einv()[i]; yv *= I.s.sc_c; }
       a.y()[i] = yv;
     }
@@ -588,14 +588,18 @@ QPN double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const
  * the loop body of qpalm_solve (src/qpalm.c:484-711) for one QP; runs at most `budget` iterations
  * =========================================================================================== */
 template <int RPT>
-QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, IterShared &I, char *lds) {
+QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, IterShared &I, char *lds) {
   const qpg_settings &st = *V.settings;
   QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x;
   double *L = V.L + (size_t)slot * V.ld * V.nfac, *Dg = V.Dg + (size_t)slot * V.nfac, *Wst = V.Wst + (size_t)slot * V.wst_stride;
   double *LQ = V.LQ ? V.LQ + (size_t)slot * V.ld * V.nfac : nullptr, *DgQ = V.DgQ ? V.DgQ + (size_t)slot * V.nfac : nullptr;
   __syncthreads();
-  if (tid == 0) I.s = V.sc[b];
+  if (tid == 0) {
+    I.s = V.sc[b];
+    /* qpalm_solve on a finished workspace starts over (src/qpalm.c:401-420 re-initialises its locals) */
+    if (fresh && I.s.done) { I.s.done = 0; I.s.in_solve = 0; }
+  }
   __syncthreads();
   if (I.s.done) return;
   const long long t_launch = QP_CLOCK();

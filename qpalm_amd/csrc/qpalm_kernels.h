@@ -269,7 +269,8 @@ QPD void qp_place_panel_wave(const qpg_view &V, QpShared &S) {
 }
 
 /* The persistent solver: workgroup `blockIdx.x` owns factor slot `blockIdx.x` and pulls QPs either
- * statically (b = blockIdx.x, resumable, needs B <= grid) or from an atomic work queue. */
+ * statically (b = blockIdx.x, resumable, needs B <= grid) or from an atomic work queue (dynamic & 1).  dynamic & 2: a
+ * fresh qpalm_solve -- QPs whose previous solve has finished start over. */
 template <int RPT>
 __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_solve(qpg_view V, int budget, int dynamic) {
   __shared__ IterShared I;
@@ -279,14 +280,14 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_solve(qpg_view V, int bud
    * or the atomic work queue only differ in how the next QP index is obtained */
   int b = blockIdx.x - gridDim.x;
   while (true) {
-    if (dynamic) {
+    if (dynamic & 1) {
       __syncthreads();
       if (threadIdx.x == 0) I.S.ibc[0] = atomicAdd(V.queue, 1);
       __syncthreads();
       b = QP_UNIFORM(I.S.ibc[0]);
     } else b += gridDim.x;
     if (b >= V.B) break;
-    dev_solve<RPT>(V, b, blockIdx.x, budget, I, lds);
+    dev_solve<RPT>(V, b, blockIdx.x, budget, dynamic & 2, I, lds);
   }
 }
 

@@ -99,6 +99,10 @@ class QpalmBatch:
         ys = f64(y).reshape(self.B, self.m) if y is not None else None
         self._check(self.L.qpg_batch_warm_start(self.h, fptr(xs) if xs is not None else None, fptr(ys) if ys is not None else None))
 
+    def warm_start_last(self):
+        """qpalm_warm_start of every QP with its own last solution, device-resident (the MPC receding-horizon step)."""
+        self._check(self.L.qpg_batch_warm_start_last(self.h))
+
     def solve(self):
         self._check(self.L.qpg_batch_solve(self.h))
 

@@ -114,6 +114,7 @@ static inline unsigned long long __ballot(int pred) {
 }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }

@@ -91,3 +91,32 @@ def test_mpc_sequence_at_config_scale(ctx):
             o.solve()
     for o in oracles.values():
         o.cleanup()
+
+
+def test_warm_start_last_equals_host_round_trip(ctx):
+    """qpg_batch_warm_start_last (previous solution straight from HBM) == qpalm_warm_start(solution()) bit for bit, and a
+    second qpg_batch_solve on finished QPs starts over (re-armed on the device, src/qpalm.c:401-420)."""
+    nb = sizes(ctx, 3, 64)
+    probs, dyn, rng = _plants(nb, per_plant=max(1, nb // 4))
+    st = ctx.default_settings(**ST)
+    a, b = QpalmBatch(ctx, probs, st), QpalmBatch(ctx, probs, st)
+    for bt in (a, b):
+        bt.solve()
+    xa, ya = a.solution()
+    it0 = [int(i.iter) for i in a.infos()]
+    bmin = np.stack([p.bmin for p in probs]); bmax = np.stack([p.bmax for p in probs])
+    bmin[:, :NX] += 0.05; bmax[:, :NX] += 0.05
+    for bt in (a, b):
+        bt.update_bounds(bmin, bmax)
+    a.warm_start(xa, ya)
+    b.warm_start_last()
+    for bt in (a, b):
+        bt.solve()
+    (x1, y1), (x2, y2) = a.solution(), b.solution()
+    assert np.array_equal(x1, x2) and np.array_equal(y1, y2)
+    assert [int(i.iter) for i in a.infos()] == [int(i.iter) for i in b.infos()]
+    assert all(int(i.status_val) == 1 for i in b.infos())
+    # solve again without a warm start call: every finished QP starts a new solve from its current iterate
+    b.solve()
+    assert all(int(i.status_val) == 1 for i in b.infos()) and all(int(i.iter) >= 1 for i in b.infos())
+    assert len(it0) == nb
