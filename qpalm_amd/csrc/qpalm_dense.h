@@ -19,6 +19,7 @@
 
 #ifdef QPALM_EMU
 #define QP_WAVE_SYNC() emu_wave_sync()
+#define QP_LDS_VBASE(p) (p)
 #define QP_SCHED_BARRIER() do { } while (0)
 #define QP_SETPRIO(p) do { } while (0)
 /* LDS flags between wavefronts of one workgroup (helper wave of the update sweep) */
@@ -47,6 +48,14 @@ static __device__ __forceinline__ int qp_flag_load_(int __attribute__((address_s
 /* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
 #define QP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define QP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+/* an LDS address the compiler must keep in ONE VGPR (it otherwise hoists every "base + constant" of a loop into its own SGPR
+ * and pays a v_mov per access to get it back into a VGPR): accesses become ds_* vbase offset:imm */
+template <class T> static __device__ __forceinline__ T QP_LDS_AS *qp_lds_vbase_(T QP_LDS_AS *p) {
+  unsigned a = (unsigned)(size_t)p;
+  asm volatile("" : "+v"(a));
+  return (T QP_LDS_AS *)(size_t)a;
+}
+#define QP_LDS_VBASE(p) qp_lds_vbase_(p)
 #endif
 
 
@@ -1127,77 +1136,41 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           /* unrolled by the queue depth: slot u of the queue is a fixed register, so the load
            * issued QD columns ago is the only one waited for (rotating the queue through register
            * moves would make every column wait for the newest load).
-           * The (-w_j, -gamma) pairs are software-pipelined by hand with register rotation, eight ranks (one "half-step")
-           * deep: right after the two FMAs of a rank have consumed its pair, the same registers are refilled with the pair
-           * of that rank slot in the NEXT half-step, so every LDS read has 16 dependent FMAs of cover and no second buffer
-           * is needed (left to the compiler, the eight reads of a half-step are issued together and waited for: ~600 clk
-           * per column measured against ~200 of FMA chain).  NGR = rank groups actually applied (ranks >= kk are exact
-           * no-ops: skipped). */
-          auto rows_of_block = [&](auto ngc) QP_ALWAYS_INLINE {
-            /* Two columns at a time, skewed by one rank: while stream A applies rank r of column c, stream B applies rank
-             * r - 1 of column c + 1 (which needs w_{r-1} after A's rank r - 1: done one step earlier).  The two streams
-             * are independent chains, so the wavefront always has an instruction ready when its dependent one is still in
-             * the pipe: sharing its SIMD with other wavefronts (which take every issue slot it leaves open, priority or
-             * not) it advances a rank of BOTH columns in the time the single chain needed for one (measured on MI355X:
-             * ~500 clk per column for the single chain of 32 FMAs even with no other workgroup on the CU).  Every entry
-             * still gets the same FMAs in the same order.  The pairs rotate through four register slots per stream. */
-            constexpr int KE = 8 * decltype(ngc)::value; /* ranks actually applied */
-            constexpr int D = 4;
-            double cfA[D][2], cfB[D][2];
+           * (Tried in round 2 and measured slower on MI355X in the full kernel, although faster in isolation: register
+           * rotation of the (-w_j, -gamma) pairs, and two columns at a time skewed by one rank.  The panel wave is bound by
+           * the number of instructions it issues, ~6.5 clk each, not by the FMA dependences.) */
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
 #pragma unroll
-            for (int r = 0; r < D; r++) {
-              cfA[r][0] = U.cwg[prv][0][r][0]; cfA[r][1] = U.cwg[prv][0][r][1];
-              cfB[r][0] = U.cwg[prv][1][r][0]; cfB[r][1] = U.cwg[prv][1][r][1];
-            }
-            auto group = [&](const int c0) QP_ALWAYS_INLINE {
+            for (int u = 0; u < QD; u++) {
+              const int c1 = c0 + u;
+              double l = q[u];
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
 #pragma unroll
-              for (int u = 0; u < QD; u += 2) {
-                const int cA = c0 + u, cB = cA + 1;
-                const int cAn = (cA + 2 < NB) ? cA + 2 : NB - 2, cBn = cAn + 1; /* past the last pair: re-reads it (unused) */
-                double lA = q[u], lB = q[u + 1];
+              for (int rb = 0; rb < K; rb += 8) {
+                if (rb >= kk) break; /* ranks >= kk are exact no-ops (w = 0, gamma = 0): skipped, wave-uniform */
+                double cw[8], cg[8];
 #pragma unroll
-                for (int r = 0; r <= KE; r++) {
-                  const int ra = r & (K - 1), rb = (r - 1) & (K - 1);
-                  if (r < KE) wrow[ra] = QP_FMA(cfA[r % D][0], lA, wrow[ra]);
-                  if (r >= 1) wrow[rb] = QP_FMA(cfB[(r - 1) % D][0], lB, wrow[rb]);
-                  if (r < KE) lA = QP_FMA(cfA[r % D][1], wrow[ra], lA);
-                  if (r >= 1) lB = QP_FMA(cfB[(r - 1) % D][1], wrow[rb], lB);
-                  QP_SCHED_BARRIER();
-                  if (r < KE) {
-                    const int rn = (r + D < KE) ? r + D : r + D - KE, cn = (r + D < KE) ? cA : cAn;
-                    cfA[r % D][0] = U.cwg[prv][cn][rn][0]; cfA[r % D][1] = U.cwg[prv][cn][rn][1];
+                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                  if (rb + r < K) {
+                    wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
+                    l = QP_FMA(cg[r], wrow[rb + r], l);
                   }
-                  if (r >= 1) {
-                    const int rn = (r - 1 + D < KE) ? r - 1 + D : r - 1 + D - KE, cn = (r - 1 + D < KE) ? cB : cBn;
-                    cfB[(r - 1) % D][0] = U.cwg[prv][cn][rn][0]; cfB[(r - 1) % D][1] = U.cwg[prv][cn][rn][1];
-                  }
-                  QP_SCHED_BARRIER();
                 }
-                rowp[(size_t)cA * cstride] = lA;
-                rowp[(size_t)cB * cstride] = lB;
-                if (fuse) { /* columns Jp + cA, Jp + cB are final for this row */
-                  accp = QP_FMA(-lA, U.ys[prv][cA], accp);
-                  accp = QP_FMA(-lB, U.ys[prv][cB], accp);
-                }
-                QP_SCHED_BARRIER();
-                { /* refill AFTER the slots' registers are free: no queue rotation on the back edge */
-                  const int cpa = (cA + QD < NB) ? cA + QD : NB - 2, cpb = cpa + 1;
-                  q[u] = QP_USQ ? U.Lsq[cur][cpa][lrow] : rowp[(size_t)cpa * cstride];
-                  q[u + 1] = QP_USQ ? U.Lsq[cur][cpb][lrow] : rowp[(size_t)cpb * cstride];
-                }
-                QP_SCHED_BARRIER();
               }
-            };
-            /* first group peeled: the loop is then entered with as many memory operations in flight as
-             * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
-            group(0);
-#pragma unroll 1
-            for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+              rowp[(size_t)c1 * cstride] = l;
+              if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
+              QP_SCHED_BARRIER();
+              q[u] = QP_USQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
+              QP_SCHED_BARRIER();
+            }
           };
-          if constexpr (K > 8) {
-            if (kk > 8) rows_of_block(std::integral_constant<int, 2>{});
-            else rows_of_block(std::integral_constant<int, 1>{});
-          } else rows_of_block(std::integral_constant<int, 1>{});
+          /* first group peeled: the loop is then entered with as many memory operations in flight as
+           * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
+          group(0);
+#pragma unroll 1
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
         }
         if (QP_PANEL_TIMING && lane == 0) tdbg[8] += QP_CLOCK() - tp0;
         const long long tp1 = QP_CLOCK();
@@ -1206,6 +1179,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         /* Rolled on purpose: unrolled, the 32 lane masks and lane-derived LDS addresses become
          * long-lived values that spill under the 128-VGPR cap, and every column then waits on
          * ~5 dependent scratch loads (measured: 1830 clk/column vs ~900 for this form). */
+        double QP_LDS_AS *const wt = QP_LDS_VBASE(&U.Wt[0]);
 #pragma unroll 1
         for (int c1 = 0; c1 < jb; c1++) {
           const int ln = QP_FRESH_LANE(lane);
@@ -1213,11 +1187,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           lnext = (ln > c1 + 1 && ln < jb) ? U.Ld[cur][ln][c1 + 1] : 0.0; /* in flight during this column (column NB is padding) */
           if (ln == c1) {
 #pragma unroll
-            for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
+            for (int r = 0; r < K; r++) wt[r] = wrow[r];
           }
           QP_WAVE_SYNC();
           /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
-          const double wv = (ln < kk) ? U.Wt[ln & (K - 1)] : 0.0;
+          const double wv = (ln < kk) ? wt[ln & (K - 1)] : 0.0;
           const double d0 = qp_readlane(dreg, c1);
           const double p = sg * wv * wv * ialpha;
           double incl = p;
@@ -1242,28 +1216,18 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
           {
             double l = lcur;
-            double cf[8][2]; /* same register rotation as above, within the column (the next column's pairs do not exist yet) */
 #pragma unroll
-            for (int r = 0; r < 8; r++) { cf[r][0] = U.cwg[cur][c1][r][0]; cf[r][1] = U.cwg[cur][c1][r][1]; }
-            if (K > 8 && kk > 8) { /* ranks >= kk: exact no-ops, skipped */
+            for (int rb = 0; rb < K; rb += 8) {
+              if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
+              double cw[8], cg[8];
 #pragma unroll
-              for (int r = 0; r < 8; r++) {
-                wrow[r] = QP_FMA(cf[r][0], l, wrow[r]);
-                l = QP_FMA(cf[r][1], wrow[r], l);
-                QP_SCHED_BARRIER();
-                cf[r][0] = U.cwg[cur][c1][(8 + r) & (K - 1)][0]; cf[r][1] = U.cwg[cur][c1][(8 + r) & (K - 1)][1];
-                QP_SCHED_BARRIER();
-              }
+              for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][1] : 0.0; }
 #pragma unroll
               for (int r = 0; r < 8; r++) {
-                wrow[(8 + r) & (K - 1)] = QP_FMA(cf[r][0], l, wrow[(8 + r) & (K - 1)]);
-                l = QP_FMA(cf[r][1], wrow[(8 + r) & (K - 1)], l);
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 8; r++) {
-                wrow[r] = QP_FMA(cf[r][0], l, wrow[r]);
-                l = QP_FMA(cf[r][1], wrow[r], l);
+                if (rb + r < K) {
+                  wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
+                  l = QP_FMA(cg[r], wrow[rb + r], l);
+                }
               }
             }
             if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;

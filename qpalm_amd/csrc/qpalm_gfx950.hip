@@ -18,7 +18,10 @@
 #define QP_T 512
 #define QP_KSEL(RPT) ((RPT) <= 2 ? 16 : 8)
 #define QP_FKC 32
-#define QP_USQ 1
+#ifndef QP_USQ_512
+#define QP_USQ_512 1
+#endif
+#define QP_USQ QP_USQ_512
 #ifndef QP_UHELP_512
 #define QP_UHELP_512 0
 #endif
