@@ -541,6 +541,42 @@ def test_workgroup_shapes_and_placement_do_not_change_results(ctx):
         ctx.set_option("place_panel_wave", 1)
 
 
+def _with_long_row_and_column(p, seed):
+    """p with one dense row of A (> 16 entries: several chunks of a quarter wavefront) and one dense column"""
+    rng = np.random.default_rng(seed)
+    A = p.A_mat().tolil()
+    r, c = p.m // 3, p.n // 4
+    cols = rng.choice(p.n, size=min(p.n, 37), replace=False)
+    A[r, cols] = rng.standard_normal(len(cols))
+    rows = rng.choice(p.m, size=min(p.m, 41), replace=False)
+    A[rows, c] = rng.standard_normal(len(rows))
+    A = A.tocsc(); A.sort_indices()
+    return type(p)(p.n, p.m, p.Qp, p.Qi, p.Qx, A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64),
+                   p.q, p.bmin, p.bmax)
+
+
+def test_schur_assembly_variants_match_oracle(ctx):
+    """form_schur_narrow (a quarter wavefront per column, small QPs with short rows on average) with rows and columns of
+    A longer than one chunk of 16, against the oracle and against the one-wavefront-per-column assembly (bit for bit)."""
+    n, m = sizes(ctx, (60, 120), (200, 400))
+    probs = [_with_long_row_and_column(random_qp(n, m, seed=5300 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)), k)
+             for k in range(sizes(ctx, 2, 4))]
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    sols = []
+    try:
+        for narrow in (1, 0):
+            ctx.set_option("narrow_rows", narrow)
+            bt = _compare_solve(ctx, probs, st)
+            sols.append(bt.solution())
+            # the assembled + factorised matrix itself, on a fresh active set
+            bt.op("ldlcholQAtsigmaA")
+            sols.append(bt.factor())
+    finally:
+        ctx.set_option("narrow_rows", 1)
+    assert np.array_equal(sols[0][0], sols[2][0]) and np.array_equal(sols[0][1], sols[2][1])
+    assert np.array_equal(sols[1][0], sols[3][0]) and np.array_equal(sols[1][1], sols[3][1])
+
+
 def test_mpc_qps_match_oracle(ctx):
     T = sizes(ctx, 3, 10)
     probs = [random_mpc_qp(T=T, nx=sizes(ctx, 4, 10), nu=sizes(ctx, 2, 5), seed=k) for k in range(2)]
