@@ -10,6 +10,7 @@ come only from reduction order / FMA inside SpMV, dot products and the LDL^T ker
   * active sets, entering/leaving lists, iteration counts and statuses: exact.
 """
 import numpy as np
+import scipy.sparse as sp
 import pytest
 
 from oracle import binding as ob
@@ -21,7 +22,10 @@ RTOL = 1e-9
 
 
 def rel(a, b):
-    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1.0, np.max(np.abs(b)))
+    a, b = np.asarray(a), np.asarray(b)
+    if a.size == 0 and b.size == 0:
+        return 0.0
+    return np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
 
 
 def oracle_for(p, st):
@@ -575,6 +579,22 @@ def test_schur_assembly_variants_match_oracle(ctx):
         ctx.set_option("narrow_rows", 1)
     assert np.array_equal(sols[0][0], sols[2][0]) and np.array_equal(sols[0][1], sols[2][1])
     assert np.array_equal(sols[1][0], sols[3][0]) and np.array_equal(sols[1][1], sols[3][1])
+
+
+def test_no_constraints_and_single_constraint(ctx):
+    """Edge cases of the shapes: m = 0 (A is n x 0: the loop never has an active row; x = -Q^{-1} q) and m = 1."""
+    base = random_qp(30, 10, seed=7, density_A=0.2, density_M=0.1)
+    QPt = type(base)
+    p0 = QPt(base.n, 0, base.Qp, base.Qi, base.Qx, np.zeros(base.n + 1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0),
+             base.q, np.zeros(0), np.zeros(0))
+    row = np.zeros(base.n); row[[2, 7, 11]] = [1.0, -2.0, 0.5]
+    A1 = sp.csc_matrix(row[None, :])
+    p1 = QPt(base.n, 1, base.Qp, base.Qi, base.Qx, A1.indptr.astype(np.int64), A1.indices.astype(np.int64), A1.data.astype(np.float64),
+             base.q, np.array([-0.05]), np.array([0.05]))
+    st = dict(eps_abs=1e-8, eps_rel=1e-8, verbose=0)
+    bt = _compare_solve(ctx, [p0], st)
+    assert rel(bt.solution()[0][0], np.linalg.solve(p0.Q_full().toarray(), -p0.q)) <= 1e-9
+    _compare_solve(ctx, [p1], st)
 
 
 def test_mpc_qps_match_oracle(ctx):
