@@ -53,7 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="random-1000", choices=("random-1000", "mpc-160"))
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "4096")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "8192")),
                     help="QPs per GPU (512 resident factor slots = workgroups; the rest queue up behind them)")
     ap.add_argument("--n", type=int, default=0, help="random workload: number of variables (default 1000)")
     ap.add_argument("--m", type=int, default=0, help="random workload: number of constraints (default 2 n)")
