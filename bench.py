@@ -272,8 +272,11 @@ def worker(args):
         wl = "mpc-160: batch of %d MPC QPs per GPU (T=10, nx=10, nu=5: n=%d m=%d nnz(A)=%d), eps 1e-6, scaling 10; every step moves " \
              "the initial states (update_bounds) and warm-starts from the previous solution" % (B, n, m, int(probs[0].Ap[-1]))
     bt = QpalmBatch(ctx, probs, ctx.default_settings(**settings_kw))   # upload + Ruiz scaling: not timed
-    bmin_all = np.stack([p.bmin for p in probs])
-    bmax_all = np.stack([p.bmax for p in probs])
+    # the arrays that cross PCIe every step of the MPC loop live in page-locked host memory (qpg_host_alloc)
+    bmin_all, bmax_all = ctx.pinned_array((B, m)), ctx.pinned_array((B, m))
+    bmin_all[:] = np.stack([p.bmin for p in probs])
+    bmax_all[:] = np.stack([p.bmax for p in probs])
+    sol_out = (ctx.pinned_array((B, n)), ctx.pinned_array((B, m))) if args.workload == "mpc-160" else None
     state = {"x": None, "y": None}
 
     def gather_results():
@@ -302,7 +305,7 @@ def worker(args):
             bt.warm_start(None, None)
         bt.solve()
         if args.workload == "mpc-160":
-            state["x"], state["y"] = bt.solution()
+            state["x"], state["y"] = bt.solution(out=sol_out)
         gather_results()
 
     def barrier():

@@ -203,6 +203,10 @@ int qpg_batch_ldlsolve_all(qpg_batch *bt, qpg_int reps, float *ms_per_rep);
  * read + write counted): the yardstick quoted next to the 8 TB/s spec figure */
 int qpg_ctx_hbm_copy_gbs(qpg_ctx *ctx, size_t bytes, qpg_int reps, float *gbs);
 int qpg_ctx_hbm_read_gbs(qpg_ctx *ctx, size_t bytes, qpg_int reps, float *gbs); /* read-only stream (the LDL' solve only reads L) */
+/* page-locked (DMA-able) host memory for the arrays handed over every step (bounds in, solutions out); zero-filled.
+ * The reference has no counterpart: it runs where its data is. */
+int qpg_host_alloc(qpg_ctx *ctx, size_t bytes, void **out);
+int qpg_host_free(qpg_ctx *ctx, void *p);
 
 #ifdef __cplusplus
 }

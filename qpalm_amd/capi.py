@@ -116,6 +116,8 @@ def load(path=None):
     L.qpg_batch_ldlsolve_all.argtypes = [C.c_void_p, c_int, C.POINTER(C.c_float)]
     L.qpg_ctx_hbm_copy_gbs.argtypes = [C.c_void_p, C.c_size_t, c_int, C.POINTER(C.c_float)]
     L.qpg_ctx_hbm_read_gbs.argtypes = [C.c_void_p, C.c_size_t, c_int, C.POINTER(C.c_float)]
+    L.qpg_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.qpg_host_free.argtypes = [C.c_void_p, C.c_void_p]
     _LIBS[path] = L
     return L
 
@@ -132,7 +134,7 @@ SYMBOLS = [
     "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints", "qpg_ldldowndate_leaving_constraints",
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
     "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
-    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_ctx_hbm_read_gbs", "qpg_batch_set_problem_sized",
+    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_ctx_hbm_read_gbs", "qpg_host_alloc", "qpg_host_free", "qpg_batch_set_problem_sized",
 ]
 
 

@@ -86,8 +86,11 @@ template <class K> static void rt_allow_lds(K kernel, size_t shmem) {
 #define RT_DEVICE_INIT(device, why) rt_device_init((device), (why))
 #define RT_MALLOC(pp, bytes) rt_check(hipMalloc((void **)(pp), (bytes)), "hipMalloc")
 #define RT_FREE(p) (void)hipFree(p)
+#define RT_HOST_ALLOC(pp, bytes) rt_check(hipHostMalloc((void **)(pp), (bytes), hipHostMallocDefault), "hipHostMalloc")
+#define RT_HOST_FREE(p) (void)hipHostFree(p)
 #define RT_MEMCPY_H2D(dst, src, bytes) rt_check(hipMemcpy((void *)(dst), (const void *)(src), (bytes), hipMemcpyHostToDevice), "hipMemcpy H2D")
 #define RT_MEMCPY_D2H(dst, src, bytes) rt_check(hipMemcpy((void *)(dst), (const void *)(src), (bytes), hipMemcpyDeviceToHost), "hipMemcpy D2H")
+#define RT_MEMCPY2D_H2D(dst, dpitch, src, spitch, width, height) rt_check(hipMemcpy2D((void *)(dst), (dpitch), (const void *)(src), (spitch), (width), (height), hipMemcpyHostToDevice), "hipMemcpy2D H2D")
 #define RT_MEMSET(dst, val, bytes) rt_check(hipMemset((void *)(dst), (val), (bytes)), "hipMemset")
 #define RT_SYNC() rt_sync()
 #define RT_STICKY() (g_rt_sticky)

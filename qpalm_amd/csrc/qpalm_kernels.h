@@ -292,15 +292,29 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_solve(qpg_view V, int bud
 }
 
 /* qpalm_update_bounds, device part (qpalm.c:819-826): the host wrote the raw bounds */
-__global__ __launch_bounds__(QP_T) void k_update_bounds(qpg_view V, int has_bmin, int has_bmax, const int *skip) {
+/* The raw bounds are staged in the line-search scratch (ls_key: [b][0..m) = bmin, [b][m..2m) = bmax; idle between solves).
+ * Validation (bmin <= bmax, qpalm.c:806-817) happens here too: bad[b] = 1 leaves the QP's bounds untouched. */
+__global__ __launch_bounds__(QP_T) void k_update_bounds(qpg_view V, int has_bmin, int has_bmax, int *bad) {
+  __shared__ int s_bad;
   for (int b = blockIdx.x; b < V.B; b += gridDim.x) {
-    if (skip && skip[b]) continue;
     const QpArrays a = qp_arrays(V, b);
-    if (V.sc[b].has_scaling)
-      for (int i = threadIdx.x; i < a.m; i += QP_T) {
-        if (has_bmin) a.bmin()[i] = a.E()[i] * a.bmin()[i];
-        if (has_bmax) a.bmax()[i] = a.E()[i] * a.bmax()[i];
-      }
+    const double *smin = V.ls_key + (size_t)b * V.ls_stride, *smax = smin + V.m; /* batch stride m: rows of the host arrays */
+    int mine = 0;
+    if (has_bmin && has_bmax)
+      for (int i = threadIdx.x; i < a.m; i += QP_T) mine |= (smin[i] > smax[i]) ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    if (mine) s_bad = 1;
+    __syncthreads();
+    const int isbad = s_bad;
+    if (threadIdx.x == 0) bad[b] = isbad;
+    if (isbad) continue;
+    const bool sc = V.sc[b].has_scaling != 0;
+    for (int i = threadIdx.x; i < a.m; i += QP_T) {
+      if (has_bmin) a.bmin()[i] = sc ? a.E()[i] * smin[i] : smin[i];
+      if (has_bmax) a.bmax()[i] = sc ? a.E()[i] * smax[i] : smax[i];
+    }
   }
 }
 

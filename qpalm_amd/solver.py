@@ -53,6 +53,22 @@ class Context:
             raise QpgError(rc, self.L.qpg_last_error().decode())
         return float(g.value)
 
+    def pinned_array(self, shape):
+        """float64 array of zeros in page-locked host memory (qpg_host_alloc): hand bounds over / take solutions in such
+        arrays and the copies are DMA transfers.  The memory lives as long as the array (and this context)."""
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        count = int(np.prod(shape)) if shape else 1
+        p = C.c_void_p()
+        rc = self.L.qpg_host_alloc(self.h, max(count, 1) * 8, C.byref(p))
+        if rc != 0:
+            raise QpgError(rc, self.L.qpg_last_error().decode())
+        buf = (C.c_double * max(count, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.float64, count=count).reshape(shape)
+        ctx_l, ctx_h, addr = self.L, self.h, p.value
+        import weakref
+        weakref.finalize(buf, lambda: ctx_l.qpg_host_free(ctx_h, C.c_void_p(addr)))
+        return arr
+
     def hbm_read_gbs(self, nbytes=1 << 30, reps=5):
         """measured read-only streaming bandwidth of the device (GB/s)"""
         g = C.c_float(0.0)
@@ -151,8 +167,15 @@ class QpalmBatch:
         self._check(self.L.qpg_batch_get_stats(self.h, int(b), C.byref(out)))
         return out
 
-    def solution(self):
-        x, y = np.zeros((self.B, self.n)), np.zeros((self.B, self.m))
+    def solution(self, out=None):
+        """(x [B][n], y [B][m]); out = (x, y): C-contiguous float64 arrays to fill (e.g. Context.pinned_array: no page
+        faults, DMA at PCIe rate) instead of fresh ones"""
+        if out is None:
+            x, y = np.zeros((self.B, self.n)), np.zeros((self.B, self.m))
+        else:
+            x, y = out
+            assert x.shape == (self.B, self.n) and y.shape == (self.B, self.m) and x.dtype == np.float64 and y.dtype == np.float64
+            assert x.flags.c_contiguous and y.flags.c_contiguous
         self._check(self.L.qpg_batch_get_solution(self.h, fptr(x), fptr(y)))
         return x, y
 

@@ -120,3 +120,27 @@ def test_warm_start_last_equals_host_round_trip(ctx):
     b.solve()
     assert all(int(i.status_val) == 1 for i in b.infos()) and all(int(i.iter) >= 1 for i in b.infos())
     assert len(it0) == nb
+
+
+def test_pinned_host_arrays(ctx):
+    """qpg_host_alloc: bounds handed over from, and solutions taken into, page-locked arrays give the same results."""
+    nb = sizes(ctx, 3, 32)
+    probs, dyn, rng = _plants(nb, per_plant=max(1, nb // 4))
+    bt = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
+    bt.solve()
+    x, y = bt.solution()
+    px, py = ctx.pinned_array((nb, probs[0].n)), ctx.pinned_array((nb, probs[0].m))
+    assert px.shape == x.shape and not px.any()
+    rx, ry = bt.solution(out=(px, py))
+    assert rx is px and np.array_equal(px, x) and np.array_equal(py, y)
+    bmin, bmax = ctx.pinned_array((nb, probs[0].m)), ctx.pinned_array((nb, probs[0].m))
+    bmin[:] = np.stack([p.bmin for p in probs]); bmax[:] = np.stack([p.bmax for p in probs])
+    bmin[:, :NX] += 0.02; bmax[:, :NX] += 0.02
+    other = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
+    other.solve()
+    for b in (bt, other):
+        b.warm_start_last()
+    bt.update_bounds(bmin, bmax)
+    other.update_bounds(np.array(bmin), np.array(bmax))
+    bt.solve(); other.solve()
+    assert np.array_equal(bt.solution()[0], other.solution()[0])
