@@ -395,6 +395,10 @@ def worker(args):
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes,
                          "measured_copy_GBps": copy_gbs, "measured_read_GBps": read_gbs, "frac_of_measured_copy": achieved / copy_gbs,
+                         # the HBM bytes the launch really moved (PMC) per second, against the same yardsticks: how far the
+                         # kernel is from the bandwidth this chip delivers to a plain copy
+                         "traffic_GBps": (traffic / (kms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_measured_copy": (traffic / (kms * 1e-3) / 1e9 / copy_gbs) if traffic else None,
                          "bytes_note": "update bytes = 16 B x entries of L[:, J0:] actually swept (device counter), not the 8d upper bound",
                          "phases": phases},
             "ldl_solve": {"kernel": "k_ldlsolve_all", "qps": nsl, "ms": ms_ldl, "bytes": ldl_bytes,
