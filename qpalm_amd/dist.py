@@ -37,9 +37,11 @@ def shard_indices(nqp, world, rank):
 
 def info_matrix(batch):
     """[B][len(INFO_FIELDS)] fp64: the QPALMInfo records of the batch (one device-to-host copy), ready for the gather"""
-    out = np.zeros((batch.B, len(INFO_FIELDS)))
-    for b, info in enumerate(batch.infos()):
-        out[b] = [float(getattr(info, k)) for k in INFO_FIELDS]
+    from .capi import Info
+    rec = np.frombuffer(batch.infos(), dtype=np.dtype(Info), count=batch.B)   # structured view of the ctypes array: no Python loop
+    out = np.empty((batch.B, len(INFO_FIELDS)))
+    for j, k in enumerate(INFO_FIELDS):
+        out[:, j] = rec[k]
     return out
 
 
