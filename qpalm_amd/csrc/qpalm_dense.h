@@ -646,7 +646,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
   SolveLds QP_LDS_AS &T = *(SolveLds QP_LDS_AS *)lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int NB = QP_SNB;
-  /* the right-hand side always fits: n <= 4 QP_T and lds_bytes >= 64 KB (checked by the host) */
+  /* the right-hand side always fits: 8 n <= lds_bytes (checked by the host, qpg_batch_create) */
   double QP_LDS_AS *xs = (double QP_LDS_AS *)(lds + sizeof(SolveLds));
   (void)lds_bytes;
   __syncthreads();

@@ -11,7 +11,7 @@
 #include "qpalm_types.h"
 
 /* The kernels are instantiated twice (same source, different workgroup size):
- *   qp512: 512 threads = 8 wavefronts per QP, two workgroups per CU (64 KB dynamic LDS each) -- the general instance;
+ *   qp512: 512 threads = 8 wavefronts per QP, two workgroups per CU (76 KB dynamic LDS each, QPG_LDS_DEFAULT) -- the general instance;
  *   qp256: 256 threads = 4 wavefronts per QP, FOUR workgroups per CU (38 KB dynamic LDS each) -- for small QPs (factor of
  *          at most 256 rows, e.g. the mpc-160 workload): their phases are bound by dependent-load latency, not by work
  *          per QP, so the lever is more QPs in flight per CU (measured: DESIGN.md section 7). */
