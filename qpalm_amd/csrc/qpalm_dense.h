@@ -816,13 +816,18 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
 #ifndef QP_UHELP
-#define QP_UHELP 0 /* 1: wavefront 1 ("helper") applies table s to the rows of block s+1 column pair by column pair right behind
-                      the panel wave, so that the panel wave only runs the recurrence.  Parity-green (emulator and MI355X,
-                      with the fused solve), but measured SLOWER on MI355X in both forms tried in round 2: with the helper
-                      also applying table s-1 (64 columns per phase) it finishes ~13 us after the panel wave (its loads queue
-                      behind its own stores in vmcnt); with the owners applying table s-1 (this form) the panel wave's
-                      recurrence itself slows from 0.66 to 1.09 us per column while the helper runs next to it.  Update
-                      phase 80-92 ms per QP against 70 for the default.  Opt-in: -DQP_UHELP_512=1. */
+#define QP_UHELP 0 /* 1: wavefront 1 ("helper") applies columns [0, QP_HSPLIT) of table s to the rows of block s+1 right behind the
+                      panel wave (LDS column counter), as soon as their owners have applied table s-1 and handed them over; the
+                      panel wave applies the remaining columns at the start of the next phase.  Parity-green (emulator and
+                      MI355X, fused solve included) but NOT faster on MI355X, in any of the forms tried in round 2 (same-box
+                      A/B, 4096 QPs): default 5219 QP/s; helper with QP_HSPLIT 8 / 16 / 24: 4949 / 4946-4985 / 4993.  The panel
+                      wave gets shorter (57 -> 49-52 ms per QP) but the hand-over (the owners need ~14 us of the 22 us phase
+                      for table s-1), the helper's tail and the panel wave's reads from HBM take it back.  One finding that
+                      mattered on the way: the hardware deals the wavefronts of a workgroup to the SIMDs in the order
+                      0, 2, 1, 3, ..., so "the next wavefront" is two SIMDs further -- with the panel waves of a CU's two
+                      workgroups on SIMDs 0 and 2 each helper shared a SIMD with the other workgroup's panel wave and slowed
+                      its recurrence from 0.66 to 1.09 us per column (qp_place_panel_wave now uses SIMDs 0 and 1).
+                      Opt-in: -DQP_UHELP_512=1 (qpalm_gfx950.hip). */
 #endif
 #ifndef QP_PSPLIT
 #define QP_PSPLIT 0 /* 1: the panel wave splits the ranks of the block recurrence over its two half-waves (see dense_updown).
@@ -835,13 +840,18 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
                     diagonal blocks back, so that the panel wave (the serial chain of the sweep) never waits for HBM; costs
                     16 KB of LDS.  0: the panel wave streams that square from HBM itself (the 256-thread instance: 38 KB LDS). */
 #endif
+#ifndef QP_HSPLIT
+#define QP_HSPLIT 16 /* helper variant: the helper wave applies columns [0, QP_HSPLIT) of the growing table to the rows of the next
+                        block during the phase, the panel wave the rest at the start of the next phase (multiple of 8) */
+#endif
 #ifndef QP_TQD
 #define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
 #endif
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
   double Ld[2][QP_UNB][QP_UNB + 1];
-  double Lsq[(QP_USQ && !QP_UHELP) ? 2 : 1][QP_USQ ? QP_UNB : 1][QP_UNB]; /* [parity][column of block s-1][row of block s]: the square under diagonal block s-1 */
+  double Lsq[QP_USQ ? 2 : 1][QP_USQ ? QP_UNB : 1][QP_UNB]; /* [parity][column][row]: the 32 x 32 square of L that the serial chain of the next phase
+                                                               applies a table to (staged by the owners, see the phase loop) */
   double Wd[2][QP_UNB][K + 1]; /* running w of the rows of block b: owners -> (helper wave ->) panel wave */
   double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
@@ -967,6 +977,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         if (c > c1) U.Ld[0][c][c1] = L[(size_t)(J0 + c1) * ld + (J0 + c)];
       }
       if (tid < jb0) U.dd[0][tid] = Dg[J0 + tid];
+      if (QP_UHELP && jb0 == NB) /* phase 0: the helper wave applies table 0 to the rows of block 1 */
+        for (int e = tid; e < NB * NB; e += QP_T) {
+          const int c1 = e / NB, c = e % NB;
+          U.Lsq[0][c1][c] = (J0 + NB + c < n) ? L[(size_t)(J0 + c1) * ld + (J0 + NB + c)] : 0.0;
+        }
       if (wid == 0) {
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
@@ -991,9 +1006,100 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       const int jbo = (n - Jo < NB) ? ((n - Jo > 0) ? (n - Jo) : 0) : NB;
       const int wslot = cur, hslot = prv;
       const bool own_live0 = (64 * RPT - 1 >= Jo); /* wavefront 0 still owns rows the owners work on */
+      /* helper variant: while the rows of block s+1 are wavefront 0's own, it is an owner FIRST (the helper wave waits for
+       * that hand-over) and the panel wave after; everywhere else the other way round */
+      const bool owner_first0 = QP_UHELP && own_live0 && (Jn < 64 * RPT);
+      auto owner_block = [&]() QP_ALWAYS_INLINE {
+        /* ===== owners: table s-1 on the rows below block s ======================================= */
+        const long long tt0 = QP_CLOCK();
+        bool any = false;
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jo && i < n); }
+        if (s > 0 && any) {
+          /* One column per iteration.  Branch-free body: rows that are not below the block read/write
+           * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
+           * queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four ranks at a time.
+           * Register budget <= 128 VGPRs so that two workgroups share a CU. */
+          constexpr int QD = QP_TQD;
+          /* the RPT adjacent rows of a thread are one access group: 16-byte loads/stores (RPT even),
+           * one address and one liveness per thread.  Rows n..ld-1 are padding of the panel (ld is a
+           * multiple of 8): they are carried along (w = 0 there, nobody reads them). */
+          const int i0 = tid * RPT;
+          const bool ok = (i0 >= Jo && i0 < ld);
+          qp_gdouble *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
+          const size_t cstride = ok ? (size_t)ld : 0;
+          double q[QD][RPT];
+#pragma unroll
+          for (int cc = 0; cc < QD; cc++) qp_load_rows<RPT>(rowp + (size_t)cc * cstride, q[cc]);
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
+#pragma unroll
+            for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
+              int c1 = c0 + u;
+              QP_OPAQUE(c1); /* addresses are recomputed from c1: no per-slot induction pointers (VGPR budget) */
+              double l[RPT];
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+#pragma unroll
+              for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
+#pragma unroll
+              for (int rb = 0; rb < K; rb += 4) {
+                if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
+                double cf[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { cf[r][0] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                  if (rb + r < K) {
+#pragma unroll
+                    for (int rr = 0; rr < RPT; rr++) {
+                      w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
+                      l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
+                    }
+                  }
+                }
+                QP_SCHED_BARRIER();
+              }
+              qp_store_rows<RPT>(rowp + (size_t)c1 * cstride, l);
+              if (fuse) { /* column Jp + c1 is final for these rows: its term of the forward substitution */
+                const double yv = U.ys[prv][c1];
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
+              }
+              QP_SCHED_BARRIER();
+              qp_load_rows<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
+              QP_SCHED_BARRIER();
+            }
+          };
+          group(0); /* peeled, see the panel wave's loop */
+#pragma unroll 1
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+        }
+        /* rows of block s+1 to the hand-over buffer of the next phase */
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+          const int i = tid * RPT + rr;
+          if (i >= Jo && i < Jo + jbo) {
+#pragma unroll
+            for (int r = 0; r < K; r++) U.Wd[hslot][i - Jo][r] = w[rr][r];
+            U.Wd[hslot][i - Jo][K] = acc[rr];
+            if (QP_UHELP) QP_FLAG_INC(&U.hcnt[prv]); /* after this lane's writes (LDS runs a wavefront's operations in order) */
+            if (QP_UHELP && QP_PANEL_TIMING && i == Jo) tdbg[10] += QP_CLOCK() - tph0; /* diagnostic build: when the rows are handed over */
+          }
+        }
+        if (wid == 0) {
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+            for (int r = 0; r < K; r++) U.stash[rr][r][lane] = w[rr][r];
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) U.stash_acc[rr][lane] = acc[rr];
+        }
+        if (tid == QP_T - 64) tdbg[2] += QP_CLOCK() - tt0; /* the last wavefront's rows live longest */
+      };
+      if (wid == 0 && owner_first0) owner_block();
       if (wid == 0) {
         /* ===== panel wave ===================================================================== */
         const long long tp0 = QP_CLOCK();
+        if (QP_UHELP && lane == 0) U.prog[prv] = 0; /* re-arm the column counter of the table two phases ahead (its helper wave is done) */
         QP_SETPRIO(3); /* the serial chain of the sweep goes first on its SIMD */
 #if QP_PSPLIT
         /* ---- rank-split panel wave.  The block has 32 rows but a wavefront has 64 lanes: the low half-wave works on
@@ -1123,16 +1229,21 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[wslot][lane][r] : 0.0;
         double accp = (lane < jb) ? U.Wd[wslot][lane][K] : 0.0; /* this row's substitution accumulator (fused solve) */
-        if (!QP_UHELP && s > 0) {
+        if (s > 0 && (!QP_UHELP || QP_HSPLIT < NB)) {
           /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
-           * deeper queue (one row per lane: registers to spare, and this wave is the critical path) */
-          constexpr int QD = QP_USQ ? 4 : 8;
+           * deeper queue (one row per lane: registers to spare, and this wave is the critical path).
+           * Helper variant: the helper wave has applied columns [0, QP_HSPLIT) during the last phase; the rest here, L
+           * from HBM (the staged square of this block belongs to the helper wave's phase). */
+          constexpr bool PSQ = QP_USQ && !QP_UHELP;
+          constexpr int QD = PSQ ? 4 : 8;
+          constexpr int C0 = QP_UHELP ? QP_HSPLIT : 0;
+          static_assert(C0 % QD == 0 && (NB - C0) % QD == 0, "QP_HSPLIT: a multiple of the queue depth");
           qp_gdouble *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
           const size_t cstride = (lane < jb) ? (size_t)ld : 0;
           const int lrow = lane & (NB - 1);
           double q[QD];
 #pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[cc] = QP_USQ ? U.Lsq[cur][cc][lrow] : rowp[(size_t)cc * cstride];
+          for (int cc = 0; cc < QD; cc++) q[cc] = PSQ ? U.Lsq[cur][C0 + cc][lrow] : rowp[(size_t)(C0 + cc) * cstride];
           /* unrolled by the queue depth: slot u of the queue is a fixed register, so the load
            * issued QD columns ago is the only one waited for (rotating the queue through register
            * moves would make every column wait for the newest load).
@@ -1162,15 +1273,15 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               rowp[(size_t)c1 * cstride] = l;
               if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
               QP_SCHED_BARRIER();
-              q[u] = QP_USQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
+              q[u] = PSQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
               QP_SCHED_BARRIER();
             }
           };
           /* first group peeled: the loop is then entered with as many memory operations in flight as
            * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
-          group(0);
+          group(C0);
 #pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+          for (int c0 = C0 + QD; c0 < NB; c0 += QD) group(c0);
         }
         if (QP_PANEL_TIMING && lane == 0) tdbg[8] += QP_CLOCK() - tp0;
         const long long tp1 = QP_CLOCK();
@@ -1267,94 +1378,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live0 ? U.stash_acc[rr][lane] : 0.0;
         QP_SETPRIO(0);
         if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
-        if (QP_PANEL_TIMING && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
+        if (QP_PANEL_TIMING && !QP_UHELP && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
         tpe = QP_CLOCK();
       }
-      if (wid != 0 || own_live0) {
-        /* ===== owners: table s-1 on the rows below block s ======================================= */
-        const long long tt0 = QP_CLOCK();
-        bool any = false;
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jo && i < n); }
-        if (s > 0 && any) {
-          /* One column per iteration.  Branch-free body: rows that are not below the block read/write
-           * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
-           * queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four ranks at a time.
-           * Register budget <= 128 VGPRs so that two workgroups share a CU. */
-          constexpr int QD = QP_TQD;
-          /* the RPT adjacent rows of a thread are one access group: 16-byte loads/stores (RPT even),
-           * one address and one liveness per thread.  Rows n..ld-1 are padding of the panel (ld is a
-           * multiple of 8): they are carried along (w = 0 there, nobody reads them). */
-          const int i0 = tid * RPT;
-          const bool ok = (i0 >= Jo && i0 < ld);
-          qp_gdouble *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
-          const size_t cstride = ok ? (size_t)ld : 0;
-          double q[QD][RPT];
-#pragma unroll
-          for (int cc = 0; cc < QD; cc++) qp_load_rows<RPT>(rowp + (size_t)cc * cstride, q[cc]);
-          auto group = [&](const int c0) QP_ALWAYS_INLINE {
-#pragma unroll
-            for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
-              int c1 = c0 + u;
-              QP_OPAQUE(c1); /* addresses are recomputed from c1: no per-slot induction pointers (VGPR budget) */
-              double l[RPT];
-              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
-#pragma unroll
-              for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
-#pragma unroll
-              for (int rb = 0; rb < K; rb += 4) {
-                if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
-                double cf[4][2];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { cf[r][0] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                  if (rb + r < K) {
-#pragma unroll
-                    for (int rr = 0; rr < RPT; rr++) {
-                      w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
-                      l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
-                    }
-                  }
-                }
-                QP_SCHED_BARRIER();
-              }
-              qp_store_rows<RPT>(rowp + (size_t)c1 * cstride, l);
-              if (fuse) { /* column Jp + c1 is final for these rows: its term of the forward substitution */
-                const double yv = U.ys[prv][c1];
-#pragma unroll
-                for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
-              }
-              QP_SCHED_BARRIER();
-              qp_load_rows<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
-              QP_SCHED_BARRIER();
-            }
-          };
-          group(0); /* peeled, see the panel wave's loop */
-#pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
-        }
-        /* rows of block s+1 to the hand-over buffer of the next phase */
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) {
-          const int i = tid * RPT + rr;
-          if (i >= Jo && i < Jo + jbo) {
-#pragma unroll
-            for (int r = 0; r < K; r++) U.Wd[hslot][i - Jo][r] = w[rr][r];
-            U.Wd[hslot][i - Jo][K] = acc[rr];
-            if (QP_UHELP) QP_FLAG_INC(&U.hcnt[prv]); /* after this lane's writes (LDS runs a wavefront's operations in order) */
-          }
-        }
-        if (wid == 0) {
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++)
-#pragma unroll
-            for (int r = 0; r < K; r++) U.stash[rr][r][lane] = w[rr][r];
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) U.stash_acc[rr][lane] = acc[rr];
-        }
-        if (tid == QP_T - 64) tdbg[2] += QP_CLOCK() - tt0; /* the last wavefront's rows live longest */
-      }
+      if (wid != 0 || (own_live0 && !owner_first0)) owner_block();
+
       constexpr int NFREE = (QP_NW == 1) ? 0 : ((QP_UHELP && QP_NW >= 3) ? 2 : 1); /* wavefronts with a job of their own in this phase */
       if (wid >= NFREE) { /* diagonal block s+1 for the next phase */
         const int t0 = tid - 64 * NFREE, nt = QP_T - 64 * NFREE;
@@ -1367,7 +1395,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               if (s > 0) L[(size_t)(Jp + c1) * ld + (Jp + c)] = U.Ld[prv][c][c1];
               if (c < jbn) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
             }
-            if (!QP_UHELP && jbn > 0) U.Lsq[prv][c1][c] = (c < jbn) ? L[(size_t)(J + c1) * ld + (Jn + c)] : 0.0;
+            if (!QP_UHELP) { /* next phase: the panel wave applies table s to the rows of block s+1 */
+              if (jbn > 0) U.Lsq[prv][c1][c] = (c < jbn) ? L[(size_t)(J + c1) * ld + (Jn + c)] : 0.0;
+            } else if (jbn == NB) { /* next phase: the helper wave applies table s+1 to the rows of block s+2 */
+              U.Lsq[prv][c1][c] = (Jn + NB + c < n) ? L[(size_t)(Jn + c1) * ld + (Jn + NB + c)] : 0.0;
+            }
           }
         } else {
           for (int e = t0; e < jbn * jbn; e += nt) {
@@ -1405,90 +1437,58 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           int got = 0;
           while (got < jbn) { got = QP_FLAG_LOAD(&U.hcnt[prv]); if (got < jbn) QP_SPIN_PAUSE(); }
         }
+        if (QP_PANEL_TIMING && lane == 0) tdbg[8] += QP_CLOCK() - th0; /* diagnostic build: the helper's wait for the hand-over */
         double wrow[K];
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jbn) ? U.Wd[hs][lane][r] : 0.0;
         double hacc = (lane < jbn) ? U.Wd[hs][lane][K] : 0.0;
         const int lrow = lane & (NB - 1);
-        constexpr int QD = 8;
+        constexpr int QD = 4;
         const size_t cstride = (lane < jbn) ? (size_t)ld : 0;
-        /* one table applied to the rows: two columns at a time, skewed by one rank (two independent FMA chains), the
-         * (-w_j, -gamma) pairs rotating through four register slots per chain -- see rows_of_block above */
-        auto apply_table = [&](auto kec, auto passc) QP_ALWAYS_INLINE {
-          constexpr int KE = decltype(kec)::value; /* ranks actually applied (ranks >= kk are exact no-ops) */
-          constexpr int pass = decltype(passc)::value; /* 0: table s-1 (complete), 1: table s (growing) */
-          constexpr int D = 4;
-          const int tb = pass ? cur : prv;
-          qp_gdouble *rowp = (lane < jbn) ? (L + (size_t)(pass ? J : Jp) * ld + Jn + lane) : (dummy + lane);
+        { /* table s, column by column as the panel wave publishes it; L from the square the owners staged in LDS last
+           * phase, final entries back to HBM and (fused solve) back into the same LDS cell for the terms added below */
+          qp_gdouble *rowp = (lane < jbn) ? (L + (size_t)J * ld + Jn + lane) : (dummy + lane);
           double q[QD];
 #pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[cc] = rowp[(size_t)cc * cstride];
-          int avail = pass ? 0 : NB; /* columns of the table known to be published */
-          double cfA[D][2], cfB[D][2];
-          auto group = [&](const int c0, const bool first) QP_ALWAYS_INLINE {
+          for (int cc = 0; cc < QD; cc++) q[cc] = U.Lsq[cur][cc][lrow];
+          int avail = 0; /* columns of the table known to be published */
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
 #pragma unroll
-            for (int u = 0; u < QD; u += 2) {
-              const int cA = c0 + u, cB = cA + 1;
-              const int cAn = (cA + 2 < NB) ? cA + 2 : NB - 2, cBn = cAn + 1;
-              while (avail <= cB) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= cB) QP_SPIN_PAUSE(); }
-              if (pass || (first && u == 0)) {
-                /* growing table: the next pair of columns cannot be read ahead, the slots are filled per pair */
+            for (int u = 0; u < QD; u++) {
+              const int c1 = c0 + u;
+              while (avail <= c1) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= c1) QP_SPIN_PAUSE(); }
+              double l = q[u];
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
 #pragma unroll
-                for (int r = 0; r < D; r++) {
-                  cfA[r][0] = U.cwg[tb][cA][r][0]; cfA[r][1] = U.cwg[tb][cA][r][1];
-                  cfB[r][0] = U.cwg[tb][cB][r][0]; cfB[r][1] = U.cwg[tb][cB][r][1];
+              for (int rb = 0; rb < K; rb += 8) {
+                if (rb >= kk) break; /* ranks >= kk are exact no-ops: skipped, wave-uniform */
+                double cw[8], cg[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][1] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                  if (rb + r < K) {
+                    wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
+                    l = QP_FMA(cg[r], wrow[rb + r], l);
+                  }
                 }
               }
-              double lA = q[u], lB = q[u + 1];
-#pragma unroll
-              for (int r = 0; r <= KE; r++) {
-                const int ra = r & (K - 1), rb = (r - 1) & (K - 1);
-                if (r < KE) wrow[ra] = QP_FMA(cfA[r % D][0], lA, wrow[ra]);
-                if (r >= 1) wrow[rb] = QP_FMA(cfB[(r - 1) % D][0], lB, wrow[rb]);
-                if (r < KE) lA = QP_FMA(cfA[r % D][1], wrow[ra], lA);
-                if (r >= 1) lB = QP_FMA(cfB[(r - 1) % D][1], wrow[rb], lB);
-                QP_SCHED_BARRIER();
-                if (r < KE && (r + D < KE || !pass)) {
-                  const int rn = (r + D < KE) ? r + D : r + D - KE, cn = (r + D < KE) ? cA : cAn;
-                  cfA[r % D][0] = U.cwg[tb][cn][rn][0]; cfA[r % D][1] = U.cwg[tb][cn][rn][1];
-                }
-                if (r >= 1 && (r - 1 + D < KE || !pass)) {
-                  const int rn = (r - 1 + D < KE) ? r - 1 + D : r - 1 + D - KE, cn = (r - 1 + D < KE) ? cB : cBn;
-                  cfB[(r - 1) % D][0] = U.cwg[tb][cn][rn][0]; cfB[(r - 1) % D][1] = U.cwg[tb][cn][rn][1];
-                }
-                QP_SCHED_BARRIER();
-              }
-              rowp[(size_t)cA * cstride] = lA;
-              rowp[(size_t)cB * cstride] = lB;
-              if (fuse) {
-                if (pass) { if (lane < NB) { U.Lsq[0][cA][lane] = lA; U.Lsq[0][cB][lane] = lB; } } /* y of block s comes at the end of the phase */
-                else { hacc = QP_FMA(-lA, U.ys[prv][cA], hacc); hacc = QP_FMA(-lB, U.ys[prv][cB], hacc); }
-              }
+              rowp[(size_t)c1 * cstride] = l;
               QP_SCHED_BARRIER();
-              {
-                const int cpa = (cA + QD < NB) ? cA + QD : NB - 2, cpb = cpa + 1;
-                q[u] = rowp[(size_t)cpa * cstride];
-                q[u + 1] = rowp[(size_t)cpb * cstride];
-              }
+              q[u] = U.Lsq[cur][cpre][lrow]; /* columns ahead still hold the staged values */
+              if (fuse && lane < NB) U.Lsq[cur][c1][lane] = l; /* y of block s comes at the end of the phase */
               QP_SCHED_BARRIER();
             }
           };
-          group(0, true);
+          group(0);
 #pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0, false);
-        };
-        typedef std::integral_constant<int, 1> P1;
-        typedef std::integral_constant<int, 8> K8;
-        typedef std::integral_constant<int, 16> K16;
-        if constexpr (K > 8) {
-          if (kk > 8) apply_table(K16{}, P1{});
-          else apply_table(K8{}, P1{});
-        } else apply_table(K8{}, P1{});
+          for (int c0 = QD; c0 < QP_HSPLIT; c0 += QD) group(c0);
+        }
         if (fuse) { /* the terms of the columns of block s, once the panel wave has published y of block s */
           int avail = 0;
           while (avail <= NB) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= NB) QP_SPIN_PAUSE(); }
 #pragma unroll 8
-          for (int c = 0; c < NB; c++) hacc = QP_FMA(-U.Lsq[0][c][lrow], U.ys[cur][c], hacc);
+          for (int c = 0; c < QP_HSPLIT; c++) hacc = QP_FMA(-U.Lsq[cur][c][lrow], U.ys[cur][c], hacc);
         }
         if (lane < jbn) {
 #pragma unroll
@@ -1503,7 +1503,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live1 ? hst[(RPT * K + rr) * 64 + lane] : 0.0;
         QP_SETPRIO(0);
         QP_WAVE_SYNC(); /* every lane is past its flag reads before the counter is re-armed */
-        if (lane == 0) { U.prog[cur] = 0; U.hcnt[prv] = 0; tdbg[13] += QP_CLOCK() - th0; }
+        if (lane == 0) { U.hcnt[prv] = 0; tdbg[13] += QP_CLOCK() - th0; } /* (the column counter is re-armed by the panel wave) */
       }
       __syncthreads();
       if (QP_PANEL_TIMING && tid == 0) tdbg[11] += QP_CLOCK() - tpe;

@@ -257,10 +257,11 @@ QPD void qp_place_panel_wave(const qpg_view &V, QpShared &S) {
     const int key = QP_HW_CU_KEY() & (QPG_CU_KEYS - 1);
     const int arrival = atomicAdd(V.queue + 64 + key, 1);
     int pw = 0;
-    /* eight wavefronts per workgroup = two workgroups per CU: panel waves on SIMDs 0 and 2, so that the wavefront after
-     * the panel wave (the helper wave of the update sweep, second in priority) does not share a SIMD with the other
-     * workgroup's panel wave either */
-    const int target = (QP_NW >= 8) ? 2 * (arrival & 1) : (arrival & 3);
+    /* The hardware deals the wavefronts of a workgroup to the SIMDs in the order 0, 2, 1, 3, 0, 2, 1, 3 (rotated by where
+     * it starts; measured, tools/placement.py), so the wavefront after the panel wave -- the helper wave of the update sweep
+     * when that variant is built, second in priority -- sits two SIMDs further.  Panel waves of the two workgroups of a CU
+     * on SIMDs 0 and 1 keep all four serial wavefronts on SIMDs of their own. */
+    const int target = (QP_NW >= 8) ? (arrival & 1) : (arrival & 3);
     for (int w = QP_NW - 1; w >= 0; w--) if (S.hw_simd[w] == target) pw = w;
     S.panel_wave = V.place_panel_wave ? pw : 0;
     S.placement = key << 16 | (arrival & 255) << 8 | S.panel_wave << 4 | S.hw_simd[0];
