@@ -1,6 +1,6 @@
 """Randomised parity fuzzing: small random QPs with random shapes, bound patterns, settings (scaling, proximal, sigma, gamma,
 dual termination, KKT / Schur, inner_max_iter, max_iter) and warm starts, the engine against the oracle: status and iteration
-counts exact, x and y to 1e-8.  TEST TOOL (uses oracle/): python tools/fuzz_parity.py <seed> <cases> [hip|emu]."""
+counts exact, x and y to 1e-8.  TEST TOOL (uses oracle/): python tools/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi]."""
 import sys, numpy as np, time
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import oracle.binding as ob
@@ -12,14 +12,15 @@ backend = sys.argv[3] if len(sys.argv) > 3 else 'hip'
 ctx = Context(0, lib_path=os.path.join(ROOT, 'tests', 'emu', 'libqpalm_gfx950_emu.so')) if backend == 'emu' else Context(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+NLO, NHI = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (2, 70)   # range of n (m up to 1.7 n)
 rel = lambda a, b: (np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if a.size else 0.0
 bad = 0    # status or iteration count differs (or an exception)
 soft = 0   # same status and iterations, x or y beyond 1e-8 (seen only with sigma_init = 1e3, mostly in KKT mode: y = y + sigma (Ax - z)
            # amplifies the last bits of Ax by up to sigma_max = 1e9)
 t0 = time.time()
 for it in range(N):
-    n = int(rng.integers(2, 70)); m = int(rng.integers(1, 120))
-    dA = float(rng.choice([0.05, 0.15, 0.4, 1.0])); dM = float(rng.choice([0.02, 0.1, 0.5]))
+    n = int(rng.integers(NLO, NHI)); m = int(rng.integers(1, max(2, int(1.7 * NHI))))
+    dA = float(rng.choice([0.05, 0.15, 0.4, 1.0])) * min(1.0, 70.0 / n); dM = float(rng.choice([0.02, 0.1, 0.5])) * min(1.0, 70.0 / n)
     p = random_qp(n, m, seed=int(rng.integers(1 << 30)), density_A=dA, density_M=dM)
     # widen / tighten / equality / infinite bounds
     mode = rng.integers(0, 4)
