@@ -14,10 +14,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktm -- python3 $REPO/bench.py --workload mpc-160 --steps 5 --no-cpu > $OUT/bench_mpc160_under_kernel_trace.json 2> $OUT/ktm.err
 cd $OUT
 find kt -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_default.csv \;
+find ktm -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_mpc160.csv \;
 python3 $REPO/tools/pmc_summary.py $OUT $REPO > $OUT/k_solve_pmc_traffic.json
-rm -rf kt pmc_fetch pmc_write pmc_sq
+rm -rf kt ktm pmc_fetch pmc_write pmc_sq
 cd $REPO
 # the reported line: same build, traffic from the passes above (bench.py checks the source hash recorded in the summary)
 python bench.py --traffic-json $OUT/k_solve_pmc_traffic.json > $OUT/bench_default.json 2> $OUT/bench_default.err
