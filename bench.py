@@ -33,6 +33,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def lib_sha256(path=None):
+    """hash of the built HIP library that is loaded (a stale .so must not have another build's counters quoted for it)"""
+    import hashlib
+    from qpalm_amd import capi
+    with open(path or capi.LIB_PATH, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def source_sha256():
     """hash of the kernel + C-ABI sources: a PMC summary is only quoted for the build it was measured on"""
     import hashlib
@@ -44,7 +52,6 @@ def source_sha256():
     return h.hexdigest()
 
 
-DEFAULT_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "final", "k_solve_pmc_traffic.json")
 
 
 def parse_args(argv=None):
@@ -59,15 +66,18 @@ def parse_args(argv=None):
     ap.add_argument("--m", type=int, default=0, help="random workload: number of constraints (default 2 n)")
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kkt", action="store_true", help="factorization_method = FACTORIZE_KKT: the (n+m) x (n+m) KKT panel with row additions / deletions "
+                                                        "(what BASELINE.json config 3 literally names) instead of the Schur panel with rank updates")
     ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
     ap.add_argument("--narrow-rows", type=int, default=1, help="0: Schur assembly with one wavefront per column also for small QPs (A/B)")
     ap.add_argument("--place-panel-wave", type=int, default=1, help="0: every workgroup runs its serial chains on wavefront 0 (A/B of the SIMD placement)")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
-    ap.add_argument("--traffic-json", default=DEFAULT_TRAFFIC_JSON,
+    ap.add_argument("--traffic-json", default=None,
                     help="PMC summary written by tools/round_artifacts.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                         "command).  It is quoted only if its source hash equals the hash of the kernel sources in this tree and the "
-                         "workload matches; otherwise roofline.traffic is null")
+                         "command on the same box).  Without it roofline.traffic is null: a plain run measures no counters.  With it, "
+                         "the figure is quoted only if the hash of the kernel sources AND of the built library recorded in the summary "
+                         "equal this tree's and the workload matches")
     return ap.parse_args(argv)
 
 
@@ -105,21 +115,25 @@ def launch_ranks(args, argv):
 # ---------------------------------------------------------------------------------------------------------------
 # byte model, per QP; fp64 = 8 B, int32 indices = 4 B
 # ---------------------------------------------------------------------------------------------------------------
-def byte_model(n, m, nnzA, nnzQ):
-    nnzL = n * (n + 1) // 2                     # dense-triangle storage of the factor (natural ordering, F5)
+def byte_model(n, m, nnzA, nnzQ, nfac=None):
+    nf = nfac or n                              # rows of the factor: n (Schur) or n + m (KKT panel)
+    nnzL = nf * (nf + 1) // 2                   # dense-triangle storage of the factor (natural ordering, F5)
     b_solve = 2 * nnzL * 8 + 8 * n + 16 * n     # L twice + D + rhs/d
     b_spmv_A = nnzA * 12 + 4 * (n + 1) + 8 * (m + n)
     b_spmv_Q = nnzQ * 12 + 4 * (n + 1) + 16 * n
     b_vec = 8 * (22 * m + 18 * n) + 2 * (2 * m * 12)
-    return dict(b_solve=b_solve, b_spmv_vec_newton=2 * b_spmv_A + b_spmv_Q + b_vec, b_spmv_vec_outer=b_spmv_A + b_vec,
+    return dict(b_solve=b_solve, b_solve_forward=nnzL * 8, b_spmv_vec_newton=2 * b_spmv_A + b_spmv_Q + b_vec, b_spmv_vec_outer=b_spmv_A + b_vec,
                 b_refactor=nnzL * 8 + (nnzQ + nnzA) * 12, b_sweep_entry=16)   # a touched entry of L is read and written once
 
 
 def phase_bytes(model, st, iters):
-    """algorithmic bytes of one QP's solve by phase, from the device-side work counters"""
+    """algorithmic bytes of one QP's solve by phase, from the device-side work counters.  "solve" follows SURVEY.md section 8d (L streamed
+    twice per solve); "solve_fused_away" is the part of it this kernel never moves: the forward substitutions that ride on the last
+    update sweep (one pass over L each; the sweep's own bytes are counted by the sweep)"""
     n_newton = int(st.n_solve)
     return {
         "solve": n_newton * model["b_solve"],
+        "solve_fused_away": int(getattr(st, "n_fused_solve", 0)) * model["b_solve_forward"],
         "spmv_vectors": n_newton * model["b_spmv_vec_newton"] + max(iters - n_newton, 0) * model["b_spmv_vec_outer"],
         "factor": (int(st.n_refactor) + int(st.n_factor_Q)) * model["b_refactor"],
         "update": int(st.sweep_entries) * model["b_sweep_entry"],   # sum over sweeps of nnz(L[:, J0:]), counted by the sweep itself
@@ -146,47 +160,61 @@ def cholmod_probe():
     return {"libcholmod": lib, "cholmod_h": hdr[0] if hdr else None}
 
 
-def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
-    """Oracle ("port") on host cores, one QP per thread; bounded sample.  Reported next to the GPU figure, not a target."""
-    from concurrent.futures import ThreadPoolExecutor
+def write_problem_file(path, problems, settings_kw):
+    """the sample of the batch in the flat binary layout oracle/cpu_bench.c reads (int64 / fp64, little endian)"""
+    import ctypes as C
+    import numpy as np
     from oracle import binding as ob
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    libpath = None
-    try:  # host-tuned build of the same source (the GPU box's CPU may differ from the build host)
-        out = os.path.join("/tmp", "libqpalm_oracle_native_%d.so" % os.getpid())
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native", "OUT=" + out],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        libpath = out
-    except Exception:
-        libpath = None
+    st = ob.default_settings(**settings_kw)
+    with open(path, "wb") as f:
+        f.write(np.array([0x5150424e, len(problems)], dtype=np.int64).tobytes())
+        f.write(bytes(memoryview(C.string_at(C.addressof(st), C.sizeof(st)))))
+        for p in problems:
+            f.write(np.array([p.n, p.m, int(p.Qp[-1]), int(p.Ap[-1])], dtype=np.int64).tobytes())
+            for arr, dt in ((p.Qp, np.int64), (p.Qi, np.int64), (p.Qx, np.float64), (p.Ap, np.int64), (p.Ai, np.int64), (p.Ax, np.float64),
+                            (p.q, np.float64), (np.array([getattr(p, "c", 0.0)]), np.float64), (p.bmin, np.float64), (p.bmax, np.float64)):
+                f.write(np.ascontiguousarray(arr, dtype=dt).tobytes())
 
-    def one(p):
-        t0 = time.perf_counter()
-        o = ob.OracleQP(*p.args(), settings=ob.default_settings(**settings_kw), libpath=libpath)   # setup: copies + Ruiz scaling
-        t1 = time.perf_counter()
-        o.solve()
-        t2 = time.perf_counter()
-        st = o.status_val
-        o.cleanup()
-        return t2 - t1, t2 - t0, st
 
-    t_probe, _, _ = one(problems[0])
-    nsample = int(max(cores, min(len(problems), cores * max(1.0, budget_s / max(t_probe, 1e-3)))))
-    nsample = min(nsample, len(problems), 64 * cores)
-    sample = problems[:nsample]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        res = list(ex.map(one, sample))
-    wall = time.perf_counter() - t0
-    assert all(s == 1 for _, _, s in res)
-    probe = cholmod_probe()
-    return {"value": len(sample) / wall, "unit": "QP/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_string(),
-            "setup_plus_solve_s_per_qp": sum(t for _, t, _ in res) / len(res), "solve_s_per_qp": sum(t for t, _, _ in res) / len(res),
-            "cholmod_probe": probe,
-            "sample": "%d of the batch's %s QPs, setup + solve timed as info.run_time does (eps 1e-6), one QP per thread, "
-                      "oracle/qpalm_oracle.c (dense LDL', scalar rank-1 sweeps) built -O3 -march=native; single-QP solve %.4f s; "
-                      "no system CHOLMOD on the box (probe in cholmod_probe), so this is the restatement, not CHOLMOD"
-                      % (len(sample), workload, t_probe)}
+def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
+    """Oracle ("port") on the host cores through a C pthread harness (oracle/cpu_bench.c: one workspace per thread, no
+    Python in the timed loop); bounded sample.  Reported next to the GPU figure, not a target."""
+    cores = max(1, min(os.cpu_count() or 1, 256))
+    exe = os.path.join("/tmp", "qpalm_cpu_bench_%d" % os.getpid())
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "cpu_bench", "OUT=" + exe], stdout=subprocess.DEVNULL)
+    pfile = exe + ".bin"
+    try:
+        def run(sample, threads, passes=1):
+            write_problem_file(pfile, sample, settings_kw)
+            r = subprocess.run([exe, pfile, str(threads), str(passes)], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("cpu_bench failed (rc %d): %s %s" % (r.returncode, r.stdout[-300:], r.stderr[-300:]))
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        probe = run(problems[:1], 1)                       # one QP alone on one core
+        t_probe = probe["setup_plus_solve_s_per_qp"]
+        # ~budget_s of wall time with every core busy (a QP takes longer with all cores streaming their own factors)
+        nsample = int(max(cores, min(len(problems), cores * max(1.0, 0.5 * budget_s / max(t_probe, 1e-4)))))
+        nsample = min(nsample, len(problems))
+        passes = int(max(1, min(64, (cores * 0.5 * budget_s / max(t_probe, 1e-6)) // max(nsample, 1))))   # small QPs: the sample several times
+        res = run(problems[:nsample], cores, passes)
+    finally:
+        for fpath in (exe, pfile):
+            try:
+                os.remove(fpath)
+            except OSError:
+                pass
+    probe_lib = cholmod_probe()
+    have = bool(probe_lib["libcholmod"] and probe_lib["cholmod_h"])
+    return {"value": res["qps"], "unit": "QP/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_string(),
+            "setup_plus_solve_s_per_qp": res["setup_plus_solve_s_per_qp"], "solve_s_per_qp": res["solve_s_per_qp"],
+            "single_qp_alone_s": t_probe, "iter_mean": res["iter_mean"], "wall_s": res["wall_s"],
+            "cholmod_probe": probe_lib,
+            "sample": "%d of the batch's %s QPs x %d pass(es), setup + solve timed as info.run_time does (eps 1e-6), %d pthreads pulling QPs from a "
+                      "shared counter (oracle/cpu_bench.c, no Python in the loop), oracle/qpalm_oracle.c (dense LDL', scalar rank-1 sweeps) "
+                      "built -O3 -march=native; one QP alone on one core: %.4f s; %s"
+                      % (nsample, workload, passes, cores, t_probe,
+                         "a system CHOLMOD is present (probe in cholmod_probe) but this figure is the restatement" if have else
+                         "no system CHOLMOD on the box (probe in cholmod_probe), so this is the restatement, not CHOLMOD")}
 
 
 def kkt_spot_check(probs, xs, ys, idx, bmin_all=None, bmax_all=None):
@@ -244,6 +272,8 @@ def worker(args):
         ctx.set_option("narrow_rows", 0)
     B = args.batch
     settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    if args.kkt:
+        settings_kw["factorization_method"] = 0
     rng = np.random.default_rng(12345 + rank)
     if args.workload == "random-1000":
         n = args.n or 1000
@@ -334,15 +364,19 @@ def worker(args):
     iters = np.array([int(i.iter) for i in infos])
     n_bad = int(np.sum(statuses != 1))
     xs, ys = bt.solution()
+    import hashlib
+    sol_hash = hashlib.sha256(np.ascontiguousarray(xs).tobytes() + np.ascontiguousarray(ys).tobytes()).hexdigest()[:16]   # same-box A/B: equal results?
     kkt = kkt_spot_check(probs, xs, ys, sorted({0, B // 3, B // 2, B - 1}), bmin_all, bmax_all)
     ok = (n_bad == 0) and (kkt <= 1e-4)
-    tot = {"solve": 0, "spmv_vectors": 0, "factor": 0, "update": 0}
+    tot = {"solve": 0, "spmv_vectors": 0, "factor": 0, "update": 0, "solve_fused_away": 0}
     for b in range(B):
-        model = byte_model(n, m, int(probs[b].Ap[-1]), int(probs[b].Qp[-1]))
+        model = byte_model(n, m, int(probs[b].Ap[-1]), int(probs[b].Qp[-1]), (n + m) if args.kkt else None)
         pb = phase_bytes(model, stats[b], int(iters[b]))
         for k in tot:
             tot[k] += pb[k]
-    tot_bytes = sum(tot.values())
+    fused_away = tot.pop("solve_fused_away")
+    model_bytes = sum(tot.values())           # SURVEY.md section 8d, unfused algorithm
+    tot_bytes = model_bytes - fused_away      # what this kernel has to move: the figure the roofline fraction is quoted on
     kms = float(np.mean(kernel_ms))
     achieved = tot_bytes / (kms * 1e-3) / 1e9
     mean = lambda f: float(np.mean([f(s) for s in stats]))
@@ -354,7 +388,8 @@ def worker(args):
     def phase_gbs(nbytes, ms_per_qp):
         return nbytes / (max(ms_per_qp, 1e-9) * 1e-3 * B / conc) / 1e9
     phases = {
-        "solve": {"bytes": tot["solve"], "ms_per_qp": phase_ms["solve"], "GBps": phase_gbs(tot["solve"], phase_ms["solve"])},
+        "solve": {"bytes": tot["solve"] - fused_away, "ms_per_qp": phase_ms["solve"], "GBps": phase_gbs(tot["solve"] - fused_away, phase_ms["solve"]),
+                  "fused_away_bytes": fused_away},
         "update": {"bytes": tot["update"], "ms_per_qp": phase_ms["update"], "GBps": phase_gbs(tot["update"], phase_ms["update"])},
         "factor": {"bytes": tot["factor"], "ms_per_qp": phase_ms["factor"], "GBps": phase_gbs(tot["factor"], phase_ms["factor"]),
                    "flop": float(sum((int(s.n_refactor) + int(s.n_factor_Q)) for s in stats)) * n ** 3 / 3.0,
@@ -367,17 +402,17 @@ def worker(args):
     if rank == 0:
         copy_gbs = ctx.hbm_copy_gbs(1 << 30, 5)             # attainable ceilings on this box: copy (read + write) ...
         read_gbs = ctx.hbm_read_gbs(1 << 30, 5)             # ... and a read-only stream
-        model0 = byte_model(n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1]))
+        model0 = byte_model(n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1]), (n + m) if args.kkt else None)
         nsl = conc
         ms_ldl = bt.ldlsolve_all(reps=4)                    # stand-alone LDL' solve kernel ("HBM GB/s on LDL")
         ldl_bytes = nsl * model0["b_solve"]
         traffic = None
         traffic_src = None
-        if args.traffic_json and world == 1 and args.workload == "random-1000":
+        if args.traffic_json and world == 1:
             try:
                 with open(args.traffic_json) as f:
                     pj = json.load(f)
-                if pj["source_sha256"] == source_sha256() and (pj["batch"], pj["n"], pj["m"]) == (B, n, m):
+                if pj["source_sha256"] == source_sha256() and pj.get("lib_sha256") == lib_sha256(args.lib) and (pj["batch"], pj["n"], pj["m"]) == (B, n, m):
                     traffic = float(pj["traffic_bytes_per_launch"])
                     traffic_src = os.path.relpath(args.traffic_json, ROOT)
             except Exception:
@@ -385,27 +420,41 @@ def worker(args):
         out = {
             "metric": "QP solves/sec (batched %s)" % ("random n=%d,m=%d" % (n, m) if args.workload == "random-1000" else "MPC n=%d,m=%d, warm-started sequence" % (n, m)),
             "value": world * B * args.steps / elapsed, "unit": "QP/s",
+            # the reference's info.run_time = setup_time + solve_time (src/qpalm.c:493-495,721-723): the same rate with qpalm_setup's work
+            # of this batch added to one step (set_problem: host-side copies / format conversion, single-threaded; batch_setup: packing,
+            # upload over PCIe, Ruiz scaling + derived copies on the device); `value` is the solve rate with the batch resident in HBM
+            "value_setup_plus_solve": world * B / (elapsed / args.steps + bt.set_problem_s + bt.batch_setup_s),
+            "setup": {"set_problem_s": bt.set_problem_s, "batch_setup_s": bt.batch_setup_s,
+                      "value_device_setup_plus_solve": world * B / (elapsed / args.steps + bt.batch_setup_s)},
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl, "batch_per_gpu": B, "parallelism": "batch-shard x%d" % world,
+            "config": {"workload": wl, "batch_per_gpu": B, "n": n, "m": m, "kernel": "k_solve<%d>" % (lambda r: 1 if r <= 1 else (2 if r <= 2 else (4 if r <= 4 else 0)))(-(-(n + (m if args.kkt else 0)) // wg_threads)),
+                       "factorization": "kkt" if args.kkt else "schur", "parallelism": "batch-shard x%d" % world,
                        "update_rank_threshold": args.rank_threshold,
                        "workgroups": conc, "threads_per_workgroup": wg_threads, "lds_per_workgroup": wg_lds},
             "roofline": {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kms, "algorithmic_bytes_per_launch": tot_bytes,
+                         # SURVEY.md section 8d counts L twice per Newton solve; the forward halves that ride on the last update sweep are
+                         # never streamed by this kernel, so they are NOT in `achieved` / `frac`; the unfused model is quoted beside it
+                         "fused_away_bytes_per_launch": fused_away, "survey_model_bytes_per_launch": model_bytes,
+                         "frac_survey_model": model_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_over_algorithmic": (traffic / tot_bytes) if traffic else None,
+                         "guide_copy_GBps": 6290.0,   # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec figure
                          "measured_copy_GBps": copy_gbs, "measured_read_GBps": read_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          # the HBM bytes the launch really moved (PMC) per second, against the same yardsticks: how far the
                          # kernel is from the bandwidth this chip delivers to a plain copy
                          "traffic_GBps": (traffic / (kms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_measured_copy": (traffic / (kms * 1e-3) / 1e9 / copy_gbs) if traffic else None,
-                         "bytes_note": "update bytes = 16 B x entries of L[:, J0:] actually swept (device counter), not the 8d upper bound",
+                         "bytes_note": "update bytes = 16 B x entries of L[:, J0:] actually swept (device counter), not the 8d upper bound; solve bytes = "
+                                       "8d's two passes over L minus the forward passes fused into a sweep (device counter n_fused_solve)",
                          "phases": phases},
             "ldl_solve": {"kernel": "k_ldlsolve_all", "qps": nsl, "ms": ms_ldl, "bytes": ldl_bytes,
                           "achieved": ldl_bytes / (ms_ldl * 1e-3) / 1e9, "unit": "GB/s",
                           "frac": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "frac_of_measured_read": ldl_bytes / (ms_ldl * 1e-3) / 1e9 / read_gbs},
-            "solve_stats": {"all_solved": n_bad == 0, "kkt_spot_check_worst_rel": kkt,
+            "solve_stats": {"all_solved": n_bad == 0, "kkt_spot_check_worst_rel": kkt, "solution_sha256_16": sol_hash,
                             "iter_mean": float(iters.mean()), "iter_max": int(iters.max()),
                             "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve", "sweep_entries")},
                             "phase_ms_per_qp": phase_ms},

@@ -117,6 +117,7 @@ typedef struct {
   qpg_int placement;             /* where the QP's last solve ran: (XCC, SE, SH, CU) key << 16 | arrival index of the workgroup on
                                     that CU << 8 | panel wavefront << 4 | SIMD of wavefront 0 (qp_place_panel_wave) */
   qpg_int lobpcg_iter, nonconvex; /* LOBPCG iterations; settings->nonconvex of THIS QP after set_settings_nonconvex (:171-183) */
+  qpg_int n_fused_solve;         /* of n_solve: solves whose forward substitution was done by the last update sweep (L read once, not twice) */
 } QPGStats;
 
 typedef struct qpg_ctx qpg_ctx;
@@ -199,6 +200,10 @@ int qpg_exact_linesearch(qpg_batch *bt, qpg_int idx, qpg_float *tau);
 /* batched LDL^T solve of the current factors with right-hand side dphi (the kernel the metric's
  * "HBM GB/s on LDL" refers to): every QP of the batch, `reps` times, for benchmarking. */
 int qpg_batch_ldlsolve_all(qpg_batch *bt, qpg_int reps, float *ms_per_rep);
+/* diagnostic (tools/sweep_probe.py): every resident workgroup factorises Q + I/gamma and applies `reps` times a rank-`nranks`
+ * update + the matching downdate (rows 0 .. nranks-1 of A), i.e. the sweeps of solver_interface.c:407-441 alone under full-chip
+ * contention; the sweep's phase timers are left in QPGStats.ms_dbg, *ms = duration of the launch */
+int qpg_batch_sweep_probe(qpg_batch *bt, qpg_int reps, qpg_int nranks, float *ms);
 /* attainable HBM bandwidth of this device, measured with a plain copy kernel (best of `reps` copies of `bytes` bytes;
  * read + write counted): the yardstick quoted next to the 8 TB/s spec figure */
 int qpg_ctx_hbm_copy_gbs(qpg_ctx *ctx, size_t bytes, qpg_int reps, float *gbs);

@@ -10,8 +10,13 @@
  *   identity entry FIRST in its column (:316-324: columns of A are not sorted by row); |values| are clamped to 1e20.
  * Deliberate supersets (the reference silently drops them, which changes the QP): RANGES on E rows (MPS rule: r >= 0 ->
  * [rhs, rhs + r], r < 0 -> [rhs + r, rhs]) and bound types MI (lower = -1e20) and PL (upper = 1e20).  BV / LI / UI and
- * integrality markers are rejected with an error instead of being ignored.  Names with blanks (old fixed format) are not
- * supported: the reference converts such files first (qps_conversion.c).
+ * integrality markers are rejected with an error instead of being ignored.
+ *   Old fixed-column format (the form the Maros-Meszaros files are distributed in; names may contain blanks): detected like the
+ * reference does, by a ROWS line with a third token (qpalm_qps.c:104-108), and then read by column position -- fields 2-3, 5-12,
+ * 15-22, 25-36, 40-47, 50-61 -- with the blanks squeezed out of the names, which is what the reference's conversion to
+ * "<file>_copy.qps" does (interfaces/qps/src/qps_conversion.c:36-146) before it reads the copy; here no file is written.
+ * The reference cuts the numeric fields at columns 29-37 / 53-61; this reader takes the whole fields and accepts Fortran
+ * 'D' exponents.  A column whose entries are not contiguous and lines longer than the line buffer are errors.
  */
 #ifndef QPALM_QPS_H
 #define QPALM_QPS_H

@@ -49,7 +49,7 @@ class Stats(C.Structure):
                [(k, c_float) for k in ("gamma", "tau", "eta", "beta", "eps_pri", "eps_dua", "eps_dua_in", "sc_c",
                                        "ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")] + \
                [("ms_dbg", c_float * 16), ("sweep_entries", c_int), ("factor_reread_entries", c_int),
-                ("lobpcg_lambda", c_float), ("placement", c_int), ("lobpcg_iter", c_int), ("nonconvex", c_int)]
+                ("lobpcg_lambda", c_float), ("placement", c_int), ("lobpcg_iter", c_int), ("nonconvex", c_int), ("n_fused_solve", c_int)]
 
 
 class QpgError(RuntimeError):
@@ -114,6 +114,8 @@ def load(path=None):
     L.qpg_ldlchol_matrix.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf]
     L.qpg_sparse_matvec.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf, C.c_int, C.c_int, pf, pf]
     L.qpg_batch_ldlsolve_all.argtypes = [C.c_void_p, c_int, C.POINTER(C.c_float)]
+    if hasattr(L, "qpg_batch_sweep_probe"):
+        L.qpg_batch_sweep_probe.argtypes = [C.c_void_p, c_int, c_int, C.POINTER(C.c_float)]
     L.qpg_ctx_hbm_copy_gbs.argtypes = [C.c_void_p, C.c_size_t, c_int, C.POINTER(C.c_float)]
     L.qpg_ctx_hbm_read_gbs.argtypes = [C.c_void_p, C.c_size_t, c_int, C.POINTER(C.c_float)]
     L.qpg_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -133,7 +135,7 @@ SYMBOLS = [
     "qpg_batch_destroy", "qpg_batch_device_ptr", "qpg_batch_sync", "qpg_mat_vec", "qpg_mat_tpose_vec", "qpg_ldlchol",
     "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints", "qpg_ldldowndate_leaving_constraints",
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
-    "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
+    "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_batch_sweep_probe", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
     "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_ctx_hbm_read_gbs", "qpg_host_alloc", "qpg_host_free", "qpg_batch_set_problem_sized",
 ]
 

@@ -22,6 +22,8 @@
 #define QP_LDS_VBASE(p) (p)
 #define QP_SCHED_BARRIER() do { } while (0)
 #define QP_SETPRIO(p) do { } while (0)
+#define QP_DRAIN_LDS() do { } while (0)
+#define QP_SLEEP(n) do { } while (0)
 /* LDS flags between wavefronts of one workgroup (helper wave of the update sweep) */
 #define QP_FLAG_STORE(p, v) (*(volatile int *)(p) = (v))
 #define QP_FLAG_LOAD(p) (*(volatile int *)(p))
@@ -45,6 +47,8 @@ static __device__ __forceinline__ int qp_flag_load_(int __attribute__((address_s
 #endif
 #define QP_SPIN_PAUSE() __builtin_amdgcn_s_sleep(QP_SPIN_SLEEP)
 #define QP_SETPRIO(p) __builtin_amdgcn_s_setprio(p) /* issue priority of a wavefront on its SIMD */
+#define QP_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+#define QP_DRAIN_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory") /* diagnostic stamps: every LDS operation issued so far has returned */
 /* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
 #define QP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define QP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -67,6 +71,26 @@ QPD int qp_readlane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src)
 QPD double qp_readlane(double v, int src) { /* src is wave-uniform: v_readlane_b32 x2, result lives in SGPRs */
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
+}
+#endif
+
+/* Half-wave exchanges (v_permlane32_swap_b32: two VALU instructions per double, no LDS round trip).
+ *   qp_upper_to_lower(x): lanes 0..31 receive x of lane + 32 (lanes 32..63 keep their own x)
+ *   qp_lower_merge(q, l): lanes 0..31 keep q, lanes 32..63 receive l of lane - 32 */
+#ifdef QPALM_EMU
+QPD double qp_upper_to_lower(double x) { const int lane = threadIdx.x & 63; return emu_exchange(x, lane < 32 ? lane + 32 : lane); }
+QPD double qp_lower_merge(double q, double l) { const int lane = threadIdx.x & 63; const double t = emu_exchange(l, lane >= 32 ? lane - 32 : lane); return lane < 32 ? q : t; }
+#else
+typedef unsigned qp_uint2 __attribute__((ext_vector_type(2)));
+QPD double qp_upper_to_lower(double x) { /* swap(vdst = x, src0 = x): src0' = {lower: vdst.upper, upper: src0.upper} */
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const qp_uint2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+QPD double qp_lower_merge(double q, double l) { /* swap(vdst = q, src0 = l): vdst' = {lower: vdst.lower, upper: src0.lower} */
+  const qp_uint2 a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(q), (unsigned)__double2loint(l), false, false);
+  const qp_uint2 b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(q), (unsigned)__double2hiint(l), false, false);
+  return __hiloint2double((int)b[0], (int)a[0]);
 }
 #endif
 
@@ -287,11 +311,13 @@ QPN double form_schur(const qpg_view &V, int b, const int n, double *Lslot, cons
 /* R adjacent rows of one column: 16-byte accesses where R is even (the address is 16-byte aligned:
  * row index and leading dimension are even, slots are 256-byte aligned) */
 #ifdef QPALM_EMU
+struct qp_pair { double x, y; }; /* one (-w_j, -gamma) table entry, read with one 16-byte LDS access */
 template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) { for (int k = 0; k < R; k++) v[k] = p[k]; }
 template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) { for (int k = 0; k < R; k++) p[k] = v[k]; }
 #else
 typedef double qp_double2 __attribute__((ext_vector_type(2)));
 typedef qp_double2 __attribute__((address_space(1))) qp_gdouble2;
+typedef qp_double2 qp_pair;
 template <int R> QPD void qp_load_rows(const qp_gdouble *p, double *v) {
   if (R % 2 == 0) {
 #pragma unroll
@@ -840,6 +866,39 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
                     diagonal blocks back, so that the panel wave (the serial chain of the sweep) never waits for HBM; costs
                     16 KB of LDS.  0: the panel wave streams that square from HBM itself (the 256-thread instance: 38 KB LDS). */
 #endif
+#ifndef QP_ASPLIT
+#define QP_ASPLIT 0 /* 1 (K = 16 with the staged square, i.e. the 512-thread instance; parity-green on the emulator and on MI355X, results
+                       bit-identical): when the panel wave applies table s-1 to the 32 rows of block s -- a third of the serial chain of a
+                       sweep, lane = row, so half of the wavefront idles -- its two half-waves split the RANKS: lanes 0..31 apply ranks
+                       0..7 of column u while lanes 32..63 apply ranks 8..15 of column u-1 to the same rows (the (column, rank) dependences
+                       form a grid; l travels from the low to the high half with v_permlane32_swap, two VALU instructions, merged with the
+                       low half's next queue entry).  33 steps of 45 instructions instead of 32 columns of 82.  Round 3 measurement
+                       (tools/sweep_probe.py, 512 workgroups, 16 ranks): this part of the panel wave 343 -> 349 us per sweep, i.e. NO gain:
+                       the step is not bound by its instruction count.  Knock-outs (QP_KO) show where the time goes: the bare FMA chain is
+                       69 us per sweep with the trailing rows idle, all LDS reads / the store / the swap add 140 us, and the trailing rows'
+                       HBM loads and stores (not their FMAs, not their LDS table reads) add another 120-140 us.  Kept as an opt-in. */
+#endif
+#ifndef QP_APF
+#define QP_APF 1 /* rank-split form only: an entry of the table is refilled with the next step's entry right after its two FMAs (no gain either) */
+#endif
+#ifndef QP_OSLEEP
+#define QP_OSLEEP 0 /* > 0 (experiment): s_sleep of that many 64-cycle units after every column of the trailing-row loop */
+#endif
+#ifndef QP_ODELAY
+#define QP_ODELAY 0 /* 1 (experiment, parity-green): the owners of the trailing rows stage the next diagonal block first and then wait (LDS flag) until
+                       the panel wave has applied table s-1 to the rows of block s, so that their HBM stream overlaps the recurrence instead.
+                       Measured (tools/sweep_probe.py): the panel wave gets 5-8 % shorter, the sweep does not (1045 vs 1063-1115 us). */
+#endif
+#ifndef QP_KO
+#define QP_KO 0 /* knock-out experiments for tools/sweep_probe.py ONLY (wrong results): bits remove single pieces of the sweep to price them:
+                   1 store of l, 2 table refills, 4 half-wave swap, 8 queue refill (rank-split loop); 16 pivot-row write, 32 its read,
+                   64 rank scalars, 128 table read-back (recurrence loop); 256 trailing rows untouched, 512 their FMAs, 1024 their HBM
+                   loads and stores */
+#endif
+#ifndef QP_PROBE_NO_OWNER_TABLE
+#define QP_PROBE_NO_OWNER_TABLE 0 /* 1 (timing experiment for tools/sweep_probe.py ONLY, wrong results): the trailing rows do not read the table from
+                                     LDS -- what the panel wave's LDS round trips cost without the other wavefronts' table reads */
+#endif
 #ifndef QP_HSPLIT
 #define QP_HSPLIT 16 /* helper variant: the helper wave applies columns [0, QP_HSPLIT) of the growing table to the rows of the next
                         block during the phase, the panel wave the rest at the start of the next phase (multiple of 8) */
@@ -847,16 +906,18 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
 #ifndef QP_TQD
 #define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
 #endif
+#define QP_CWG(U, buf, col) (U).cwgz[1 + (buf) * (QP_UNB + 1) + (col)]
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
   double Ld[2][QP_UNB][QP_UNB + 1];
   double Lsq[QP_USQ ? 2 : 1][QP_USQ ? QP_UNB : 1][QP_UNB]; /* [parity][column][row]: the 32 x 32 square of L that the serial chain of the next phase
                                                                applies a table to (staged by the owners, see the phase loop) */
   double Wd[2][QP_UNB][K + 1]; /* running w of the rows of block b: owners -> (helper wave ->) panel wave */
-  double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast */
+  double cwgz[2 * QP_UNB + 3][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast: the two tables (by block parity) with an
+                                        all-zero guard column before, between and after them, so that "column -1" and "column QP_UNB" of
+                                        either table are exact no-ops (QP_CWG; the skewed half-waves of the rank-split loops read them) */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
-  double czero[K][2];          /* an all-zero table column: what an idle half-wave of the rank-split panel wave reads (exact no-ops) */
   double dd[2][QP_UNB];
   double ys[2][QP_UNB];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
   double stash_acc[RPT][64];   /* ... and wavefront 0's own row accumulators while it is the panel wave */
@@ -971,7 +1032,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         }
       }
       if (tid < 2) { U.prog[tid] = 0; U.hcnt[tid] = 0; }
-      if (tid < 2 * K) (&U.czero[0][0])[tid] = 0.0;
+      if (tid < 3 * 2 * K) (&U.cwgz[(tid / (2 * K)) * (QP_UNB + 1)][0][0])[tid % (2 * K)] = 0.0; /* the three guard columns */
       for (int e = tid; e < jb0 * jb0; e += QP_T) {
         const int c1 = e / jb0, c = e % jb0;
         if (c > c1) U.Ld[0][c][c1] = L[(size_t)(J0 + c1) * ld + (J0 + c)];
@@ -1015,7 +1076,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         bool any = false;
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jo && i < n); }
-        if (s > 0 && any) {
+        if (s > 0 && any && !(QP_KO & 256)) { /* (KO 256: the trailing rows are not touched at all) */
           /* One column per iteration.  Branch-free body: rows that are not below the block read/write
            * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
            * queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four ranks at a time.
@@ -1045,12 +1106,16 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
                 double cf[4][2];
 #pragma unroll
-                for (int r = 0; r < 4; r++) { cf[r][0] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
+                for (int r = 0; r < 4; r++) {
+                  if (QP_PROBE_NO_OWNER_TABLE) { cf[r][0] = 0.0; cf[r][1] = 0.0; QP_OPAQUE_V(cf[r][0]); QP_OPAQUE_V(cf[r][1]); continue; }
+                  cf[r][0] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][1] : 0.0;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                   if (rb + r < K) {
 #pragma unroll
                     for (int rr = 0; rr < RPT; rr++) {
+                      if (QP_KO & 512) continue; /* (KO 512: no FMAs on the trailing rows) */
                       w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
                       l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
                     }
@@ -1058,6 +1123,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 }
                 QP_SCHED_BARRIER();
               }
+              if (!(QP_KO & 1024)) /* (KO 1024: the trailing rows are neither stored nor re-loaded) */
               qp_store_rows<RPT>(rowp + (size_t)c1 * cstride, l);
               if (fuse) { /* column Jp + c1 is final for these rows: its term of the forward substitution */
                 const double yv = U.ys[prv][c1];
@@ -1065,7 +1131,9 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
               }
               QP_SCHED_BARRIER();
+              if (!(QP_KO & 1024))
               qp_load_rows<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
+              if (QP_OSLEEP > 0) QP_SLEEP(QP_OSLEEP);
               QP_SCHED_BARRIER();
             }
           };
@@ -1133,7 +1201,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           auto step = [&](const int u, const double lq) QP_ALWAYS_INLINE {
             const int col = u - hi; /* this half's column; -1 (high half, first step) and NB (low half, last step) are idle */
             const bool act = (col >= 0 && col < NB);
-            const double QP_LDS_AS *tab = act ? &U.cwg[prv][col][roff][0] : &U.czero[0][0];
+            const double QP_LDS_AS *tab = act ? &QP_CWG(U, prv, col)[roff][0] : &U.cwgz[0][0][0];
             double l = hi ? lmid : lq;
 #pragma unroll
             for (int r = 0; r < H; r++) {
@@ -1199,7 +1267,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const double dnew = d0 + incl, dprev = d0 + excl;
           const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
           const double gam = -sg2 * wv * ialpha * rdn;
-          if (s_on && (sA ? colA : colB)) { const int tc = sA ? t : t - 1; U.cwg[cur][tc][rk][0] = -wv; U.cwg[cur][tc][rk][1] = -gam; }
+          if (s_on && (sA ? colA : colB)) { const int tc = sA ? t : t - 1; QP_CWG(U, cur, tc)[rk][0] = -wv; QP_CWG(U, cur, tc)[rk][1] = -gam; }
           alpha = alpha * dnew * rdp;
           ialpha = ialpha * dprev * rdn;
           const double dA = qp_readlane(dnew, H - 1);      /* column t after the first H ranks */
@@ -1210,7 +1278,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           {
             const int col = t - lhi;
             const bool act = (col >= 0 && col < jb);
-            const double QP_LDS_AS *tab = act ? &U.cwg[cur][col][lhi * H][0] : &U.czero[0][0];
+            const double QP_LDS_AS *tab = act ? &QP_CWG(U, cur, col)[lhi * H][0] : &U.cwgz[0][0][0];
             double l = lhi ? lmid : lcur;
 #pragma unroll
             for (int r = 0; r < H; r++) {
@@ -1226,9 +1294,90 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         QP_WAVE_SYNC(); /* the final block entries were written by the high half-wave, the code below reads them lane = row */
 #else
         double wrow[K];
+        double accp;
+        constexpr bool ASPLIT = QP_ASPLIT && QP_USQ && !QP_UHELP && (K == 16);
+        if (ASPLIT && s > 0 && kk > K / 2) {
+          /* ---- rank-split form of "table s-1 applied to the rows of block s" (QP_ASPLIT).  Step u = 0 .. NB: the low half-wave
+           * (lanes 0..31, row = lane) applies ranks 0 .. H-1 of column u, the high half-wave (row = lane - 32) ranks H .. K-1 of
+           * column u-1, whose l it received from the low half at the end of the previous step.  The idle ends (high half at u = 0,
+           * low half at u = NB) read a zero guard column of the table: exact no-ops.  The high half holds the final l: it stores
+           * it and adds its term of the fused forward substitution. ------------------------------------------------------------ */
+          constexpr int H = K / 2, QD = 4;
+          const int hi = lane >> 5, prow = lane & (NB - 1), roff = hi * H;
+          double wr[H];
+#pragma unroll
+          for (int r = 0; r < H; r++) wr[r] = (prow < jb) ? U.Wd[wslot][prow][roff + r] : 0.0;
+          double acch = (prow < jb) ? U.Wd[wslot][prow][K] : 0.0;
+          const bool stl = (hi == 1 && prow < jb);
+          qp_gdouble *rows = stl ? (L + (size_t)Jp * ld + J + prow) : (dummy + lane);
+          const size_t sstride = stl ? (size_t)ld : 0;
+          /* this lane's view of table s-1: column u - hi, ranks roff .. roff + H - 1 */
+          const qp_pair QP_LDS_AS *tb = (const qp_pair QP_LDS_AS *)QP_LDS_VBASE(&QP_CWG(U, prv, -hi)[roff][0]); /* 16-byte aligned entries */
+          const double QP_LDS_AS *ysb = QP_LDS_VBASE(&U.ys[prv][0] - hi); /* ys of column u - hi (index -1 is never used with a nonzero l) */
+          double q[QD];
+#pragma unroll
+          for (int cc = 0; cc < QD; cc++) q[cc] = U.Lsq[cur][cc][prow];
+          double l = qp_lower_merge(q[0], 0.0); /* low half: l of column 0; high half: 0 (idle in step 0) */
+          /* QP_APF: an entry of the table is consumed by two FMAs and its registers are then refilled with the same rank's entry of
+           * the NEXT step, so that the LDS round trip of a step's entries (several hundred cycles with sixteen wavefronts reading
+           * tables on the same CU; measured: a step took ~650 cycles at 45 and at 82 instructions alike) overlaps the FMA chain of
+           * the step before.  One register set: double buffering spills under the 128-VGPR cap (measured: 2x slower). */
+          qp_pair cf[H];
+          double yv = 0.0;
+          auto loadcf = [&](const int u) QP_ALWAYS_INLINE {
+            const qp_pair QP_LDS_AS *tab = tb + (size_t)u * K;
+#pragma unroll
+            for (int r = 0; r < H; r++) cf[r] = tab[r];
+            /* with the table entries, so that the term of the fused forward substitution does not wait for an LDS round trip;
+             * added unconditionally (without a fused solve nobody reads the accumulators) */
+            yv = ysb[(u > 0) ? u : 1];
+          };
+          auto step = [&](const int u, const double qnext) QP_ALWAYS_INLINE {
+            if (!QP_APF) loadcf(u);
+            const int un = (u < NB) ? u + 1 : NB; /* step NB refills with its own (guard) column: never used */
+            const qp_pair QP_LDS_AS *tabn = tb + (size_t)un * K;
+#pragma unroll
+            for (int r = 0; r < H; r++) {
+              wr[r] = QP_FMA(cf[r].x, l, wr[r]);
+              l = QP_FMA(cf[r].y, wr[r], l);
+              if (QP_APF && !(QP_KO & 2)) { cf[r] = tabn[r]; QP_SCHED_BARRIER(); }
+            }
+            const int cst = (u > 0) ? u - 1 : 0; /* the high half's column (step 0: idle, l = 0) */
+            if (!(QP_KO & 1)) rows[(size_t)cst * sstride] = l;   /* final entry (high half); the low half's intermediate value goes to its dummy cell */
+            acch = QP_FMA(-l, yv, acch);       /* column Jp + u - 1 is final for this row (low half: discarded) */
+            if (QP_APF && !(QP_KO & 2)) yv = ysb[un];
+            if (QP_KO & 4) l = qnext + l; else
+            l = qp_lower_merge(qnext, l);      /* low half: l of the next column; high half: the low half's l of this column */
+          };
+          if (QP_APF) loadcf(0);
+          auto group = [&](const int c0) QP_ALWAYS_INLINE {
+#pragma unroll
+            for (int uu = 0; uu < QD; uu++) {
+              const int u = c0 + uu;
+              const int cpre = (u + 1 + QD < NB) ? u + 1 + QD : NB - 1;
+              /* the queue holds columns u + 1 .. u + QD when step u starts (slot = column % QD, a fixed register per slot; what the
+               * low half is handed after the last column is never used: it reads the guard column in step NB) */
+              step(u, q[(uu + 1) % QD]);
+              QP_SCHED_BARRIER();
+              if (!(QP_KO & 8))
+              q[(uu + 1) % QD] = U.Lsq[cur][cpre][prow]; /* refill the slot just consumed */
+              QP_SCHED_BARRIER();
+            }
+          };
+          /* the queue as the loop needs it: slots (u + 1) % QD .. hold columns u + 1 ..; column 0 has been consumed above */
+          q[0] = U.Lsq[cur][(QD < NB) ? QD : NB - 1][prow];
+          group(0);
+#pragma unroll 1
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+          step(NB, 0.0); /* drains the high half (column NB - 1); the low half reads the guard column */
+          /* back to lane = row: ranks H .. K-1 and the accumulator come down from the high half */
+#pragma unroll
+          for (int r = 0; r < H; r++) { wrow[r] = wr[r]; wrow[H + r] = qp_upper_to_lower(wr[r]); }
+          accp = qp_upper_to_lower(acch);
+        } else {
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[wslot][lane][r] : 0.0;
-        double accp = (lane < jb) ? U.Wd[wslot][lane][K] : 0.0; /* this row's substitution accumulator (fused solve) */
+        accp = (lane < jb) ? U.Wd[wslot][lane][K] : 0.0; /* this row's substitution accumulator (fused solve) */
         if (s > 0 && (!QP_UHELP || QP_HSPLIT < NB)) {
           /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
            * deeper queue (one row per lane: registers to spare, and this wave is the critical path).
@@ -1261,7 +1410,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 if (rb >= kk) break; /* ranks >= kk are exact no-ops (w = 0, gamma = 0): skipped, wave-uniform */
                 double cw[8], cg[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[prv][c1][rb + r][1] : 0.0; }
+                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][0] : 0.0; cg[r] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][1] : 0.0; }
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                   if (rb + r < K) {
@@ -1277,13 +1426,68 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               QP_SCHED_BARRIER();
             }
           };
+          /* the same with QP_APF (see the rank-split form above): an entry's registers are refilled with the next column's entry of
+           * the same rank right after its two FMAs */
+          qp_pair cf[K];
+          double yv = 0.0;
+          auto column = [&](const int c1, const double lq) QP_ALWAYS_INLINE {
+            const int cn = (c1 + 1 < NB) ? c1 + 1 : NB - 1;
+            const qp_pair QP_LDS_AS *tabn = (const qp_pair QP_LDS_AS *)&QP_CWG(U, prv, cn)[0][0];
+            double l = lq;
+#pragma unroll
+            for (int rb = 0; rb < K; rb += 8) {
+              if (rb >= kk) break;
+#pragma unroll
+              for (int r = 0; r < 8; r++) {
+                if (rb + r < K) {
+                  wrow[rb + r] = QP_FMA(cf[rb + r].x, l, wrow[rb + r]);
+                  l = QP_FMA(cf[rb + r].y, wrow[rb + r], l);
+                  cf[rb + r] = tabn[rb + r];
+                  QP_SCHED_BARRIER();
+                }
+              }
+            }
+            rowp[(size_t)c1 * cstride] = l;
+            accp = QP_FMA(-l, yv, accp); /* column Jp + c1 is final for this row (without a fused solve nobody reads the accumulators) */
+            yv = U.ys[prv][cn];
+          };
+          auto group_pf = [&](const int c0) QP_ALWAYS_INLINE {
+#pragma unroll
+            for (int u = 0; u < QD; u++) {
+              const int c1 = c0 + u;
+              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+              column(c1, q[u]);
+              QP_SCHED_BARRIER();
+              q[u] = PSQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride];
+              QP_SCHED_BARRIER();
+            }
+          };
+          constexpr bool APFU = (QP_APF == 2) && PSQ; /* 2: also in this form (measured: the 16 entries + 16 running w + queue spill under the 128-VGPR cap) */
+          if (APFU) {
+            {
+              const qp_pair QP_LDS_AS *tab0 = (const qp_pair QP_LDS_AS *)&QP_CWG(U, prv, C0)[0][0];
+#pragma unroll
+              for (int rb = 0; rb < K; rb += 8) {
+                if (rb >= kk) break;
+#pragma unroll
+                for (int r = 0; r < 8; r++) if (rb + r < K) cf[rb + r] = tab0[rb + r];
+              }
+              yv = U.ys[prv][C0];
+            }
+            group_pf(C0);
+#pragma unroll 1
+            for (int c0 = C0 + QD; c0 < NB; c0 += QD) group_pf(c0);
+          } else {
           /* first group peeled: the loop is then entered with as many memory operations in flight as
            * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
           group(C0);
 #pragma unroll 1
           for (int c0 = C0 + QD; c0 < NB; c0 += QD) group(c0);
+          }
         }
-        if (QP_PANEL_TIMING && lane == 0) tdbg[8] += QP_CLOCK() - tp0;
+        }
+        if (QP_ODELAY && !QP_UHELP && s > 0) { QP_WAVE_SYNC(); if (lane == 0) QP_FLAG_STORE(&U.prog[0], s); } /* table s-1 is on the rows of block s: the owners may start */
+        if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[8] += QP_CLOCK() - tp0;
         const long long tp1 = QP_CLOCK();
         double dreg = (lane < jb) ? U.dd[cur][lane] : 1.0;          /* lane c holds the pivot of column c */
         double lnext = (lane > 0 && lane < jb) ? U.Ld[cur][lane][0] : 0.0;
@@ -1296,13 +1500,19 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const int ln = QP_FRESH_LANE(lane);
           const double lcur = lnext;
           lnext = (ln > c1 + 1 && ln < jb) ? U.Ld[cur][ln][c1 + 1] : 0.0; /* in flight during this column (column NB is padding) */
+          /* QP_PANEL_TIMING == 2 (diagnostic build): ms_dbg[8..11] = the column's four links: pivot row through LDS to lane = rank /
+           * rank scalars / table entry through LDS back to every lane / the 2 K FMAs (each stamp drains the LDS queue first) */
+          long long tc0 = 0;
+          if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); tc0 = QP_CLOCK(); }
+          if (!(QP_KO & 16))
           if (ln == c1) {
 #pragma unroll
             for (int r = 0; r < K; r++) wt[r] = wrow[r];
           }
           QP_WAVE_SYNC();
           /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
-          const double wv = (ln < kk) ? wt[ln & (K - 1)] : 0.0;
+          const double wv = (QP_KO & 32) ? wrow[0] : ((ln < kk) ? wt[ln & (K - 1)] : 0.0);
+          if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
           const double d0 = qp_readlane(dreg, c1);
           const double p = sg * wv * wv * ialpha;
           double incl = p;
@@ -1313,8 +1523,9 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const double excl = qp_row_shr<1>(incl);
           const double dnew = d0 + incl, dprev = d0 + excl;
           const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
-          const double gam = -sg * wv * ialpha * rdn;
-          if (ln < K) { U.cwg[cur][c1][ln][0] = -wv; U.cwg[cur][c1][ln][1] = -gam; } /* stored negated: plain FMAs below */
+          const double gam = (QP_KO & 64) ? wv : -sg * wv * ialpha * rdn;
+          if (QP_PANEL_TIMING == 2) { double gg = gam; QP_OPAQUE_V(gg); const long long t = QP_CLOCK(); if (lane == 0) tdbg[9] += t - tc0; tc0 = t; }
+          if (ln < K) { QP_CWG(U, cur, c1)[ln][0] = -wv; QP_CWG(U, cur, c1)[ln][1] = -gam; } /* stored negated: plain FMAs below */
           alpha = alpha * dnew * rdp;
           ialpha = ialpha * dprev * rdn;
           { /* final pivot of the column = value after the last rank */
@@ -1327,25 +1538,45 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
           {
             double l = lcur;
+            /* the first eight entries come back from LDS together; with more than eight ranks an entry's registers are refilled with
+             * the entry eight ranks further right after its two FMAs, so that the second group's LDS latency runs under the first
+             * group's FMA chain (it used to be requested only after that chain: a second exposed round trip per column) */
+            const qp_pair QP_LDS_AS *tab = (const qp_pair QP_LDS_AS *)&QP_CWG(U, cur, c1)[0][0];
+            qp_pair cf[8];
 #pragma unroll
-            for (int rb = 0; rb < K; rb += 8) {
-              if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
-              double cw[8], cg[8];
-#pragma unroll
-              for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][1] : 0.0; }
+            for (int r = 0; r < 8; r++) {
+              if (QP_KO & 128) { cf[r].x = wv; cf[r].y = gam; continue; }
+              cf[r] = tab[r];
+            }
+            if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[10] += t - tc0; tc0 = t; }
+            if (K > 8 && kk > 8) {
 #pragma unroll
               for (int r = 0; r < 8; r++) {
-                if (rb + r < K) {
-                  wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
-                  l = QP_FMA(cg[r], wrow[rb + r], l);
+                wrow[r] = QP_FMA(cf[r].x, l, wrow[r]);
+                l = QP_FMA(cf[r].y, wrow[r], l);
+                if (!(QP_KO & 128)) cf[r] = tab[(8 + r < K) ? 8 + r : r];
+                QP_SCHED_BARRIER();
+              }
+#pragma unroll
+              for (int r = 0; r < 8; r++) {
+                if (8 + r < K) {
+                  wrow[8 + r] = QP_FMA(cf[r].x, l, wrow[8 + r]);
+                  l = QP_FMA(cf[r].y, wrow[8 + r], l);
                 }
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; r++) {
+                wrow[r] = QP_FMA(cf[r].x, l, wrow[r]);
+                l = QP_FMA(cf[r].y, wrow[r], l);
               }
             }
             if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;
+            if (QP_PANEL_TIMING == 2) { double ll = l; QP_OPAQUE_V(ll); const long long t = QP_CLOCK(); if (lane == 0) tdbg[11] += t - tc0; }
           }
           QP_SCHED_BARRIER();
         }
-        if (QP_PANEL_TIMING && lane == 0) tdbg[9] += QP_CLOCK() - tp1;
+        if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[9] += QP_CLOCK() - tp1;
 #endif
         const long long tp2 = QP_CLOCK();
         if (fuse) { /* the diagonal block is final: y_J = L_JJ^{-1} (b_J - contributions of the earlier blocks) */
@@ -1378,12 +1609,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live0 ? U.stash_acc[rr][lane] : 0.0;
         QP_SETPRIO(0);
         if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
-        if (QP_PANEL_TIMING && !QP_UHELP && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
+        if (QP_PANEL_TIMING == 1 && !QP_UHELP && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
         tpe = QP_CLOCK();
       }
-      if (wid != 0 || (own_live0 && !owner_first0)) owner_block();
-
       constexpr int NFREE = (QP_NW == 1) ? 0 : ((QP_UHELP && QP_NW >= 3) ? 2 : 1); /* wavefronts with a job of their own in this phase */
+      auto stage_next = [&]() QP_ALWAYS_INLINE {
       if (wid >= NFREE) { /* diagonal block s+1 for the next phase */
         const int t0 = tid - 64 * NFREE, nt = QP_T - 64 * NFREE;
         if (QP_USQ) {
@@ -1409,6 +1639,22 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         }
         if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
       }
+      };
+      constexpr bool STAGE_FIRST = QP_ODELAY && !QP_UHELP && (QP_NW > 1);
+      /* the staging loads (next diagonal block, square under this block, pivots: all still untouched by this sweep) go first when
+       * the owners wait for the panel wave anyway; their HBM latency used to sit at the end of the owners' phase */
+      if (STAGE_FIRST) stage_next();
+      if (QP_ODELAY && !QP_UHELP && wid != 0 && s > 0) {
+        /* The trailing-row wavefronts start their FMA stream only when the panel wave has finished the part of its chain that
+         * is most sensitive to them (table s-1 on the rows of block s: dependent FMAs, which the three other wavefronts of its
+         * SIMD slow from ~70 to ~350 us per sweep when they stream at the same time; the recurrence that follows is bound by LDS
+         * round trips and loses far less).  They have slack: they need about half a phase. */
+        int seen = 0;
+        while (seen < s) { seen = QP_FLAG_LOAD(&U.prog[0]); if (seen < s) QP_SPIN_PAUSE(); }
+      }
+      if (wid != 0 || (own_live0 && !owner_first0)) owner_block();
+      if (!STAGE_FIRST) stage_next();
+
       if (QP_UHELP && wid == 1 && jbn > 0) {
         /* ===== helper wave: the 32 rows of block s+1 (lane = row, handed over by their owners in THIS phase as soon as
          * these have applied table s-1) get table s, pair of columns by pair of columns right behind the panel wave (LDS
@@ -1464,7 +1710,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 if (rb >= kk) break; /* ranks >= kk are exact no-ops: skipped, wave-uniform */
                 double cw[8], cg[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][0] : 0.0; cg[r] = (rb + r < K) ? U.cwg[cur][c1][rb + r][1] : 0.0; }
+                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? QP_CWG(U, cur, c1)[rb + r][0] : 0.0; cg[r] = (rb + r < K) ? QP_CWG(U, cur, c1)[rb + r][1] : 0.0; }
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                   if (rb + r < K) {
@@ -1506,7 +1752,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         if (lane == 0) { U.hcnt[prv] = 0; tdbg[13] += QP_CLOCK() - th0; } /* (the column counter is re-armed by the panel wave) */
       }
       __syncthreads();
-      if (QP_PANEL_TIMING && tid == 0) tdbg[11] += QP_CLOCK() - tpe;
+      if (QP_PANEL_TIMING == 1 && tid == 0) tdbg[11] += QP_CLOCK() - tpe;
     }
     if (QP_USQ) { /* the last diagonal block is still in LDS */
       const int sl = nblk - 1, Jl = J0 + sl * NB, jbl = n - Jl;

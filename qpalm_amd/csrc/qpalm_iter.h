@@ -618,7 +618,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
       I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot;
       I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
-      I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0;
+      I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0; I.s.n_fused_solve = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
       for (int k = 0; k < QPG_NDBG; k++) I.s.ticks_dbg[k] = 0;
       I.s.ticks_dbg[QPG_CNT_PLACEMENT] = I.S.placement;
@@ -898,6 +898,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
         if (action == 3) { I.s.n_factor_Q++; I.s.ticks_factor += t1 - t0; }
         if (action == 2) { if (!V.kkt) I.s.n_rank1 += nchange; I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
         I.s.n_solve++; I.s.ticks_solve += t2 - t1;
+        if (!V.kkt && (RPT > 0) && !QP_NOFUSE && action == 2) I.s.n_fused_solve++;
         I.s.last_fact = action;
       }
       QP_OPAQUE(a.b);

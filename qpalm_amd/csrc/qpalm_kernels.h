@@ -463,6 +463,39 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_ldlsolve_all(qpg_view V, 
   }
 }
 
+/* Diagnostic (tools/sweep_probe.py): every resident workgroup factorises Q + I/gamma of its QP and then applies `reps` times a
+ * rank-`nranks` update followed by the downdate with the same rows of A (constraints 0 .. nranks-1), so that variants of the
+ * update sweep can be timed under the contention of a full chip without running the solver around them.  The phase timers of
+ * the sweeps (QPGStats.ms_dbg) are left in the QP's scalars.  Not part of the solver path. */
+template <int RPT>
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_sweep_probe(qpg_view V, int reps, int nranks) {
+  __shared__ IterShared I;
+  char *lds = QP_DYN_LDS();
+  qp_place_panel_wave(V, I.S);
+  const qpg_settings &st = *V.settings;
+  for (int b = blockIdx.x; b < V.B && b < V.nslots; b += gridDim.x) {
+    const QpArrays a = qp_arrays(V, b);
+    const int n = a.n, tid = threadIdx.x, slot = blockIdx.x;
+    double *L = V.L + (size_t)slot * V.ld * V.nfac, *Dg = V.Dg + (size_t)slot * V.nfac, *Wst = V.Wst + (size_t)slot * V.wst_stride;
+    __syncthreads();
+    if (tid == 0) { I.s = V.sc[b]; for (int k = 0; k < QPG_NDBG; k++) I.s.ticks_dbg[k] = 0; }
+    __syncthreads();
+    form_schur(V, b, n, L, false, false, true, qp_gamma_init(st, I.s), I.S, lds);
+    dev_factor<RPT>(V, n, L, Dg, lds, I.s.ticks_dbg);
+    for (int i = tid; i < nranks && i < a.m; i += QP_T) { a.enter()[i] = i; a.leave()[i] = i; }
+    __syncthreads();
+    const int nr = (nranks < a.m) ? nranks : a.m;
+    const long long t0 = QP_CLOCK();
+    for (int r = 0; r < reps; r++) {
+      dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), nr, a.leave(), 0, I.S, lds, I.s.ticks_dbg);
+      dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), 0, a.leave(), nr, I.S, lds, I.s.ticks_dbg);
+    }
+    __syncthreads();
+    if (tid == 0) { I.s.ticks_update = QP_CLOCK() - t0; I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; V.sc[b] = I.s; }
+    __syncthreads();
+  }
+}
+
 /* HBM yardsticks quoted by bench.py next to the 8 TB/s spec figure ("measure the attainable
  * ceiling on the box"): a copy (read + write; every workgroup streams contiguous 32 KB pieces, eight 16-byte loads in
  * flight per lane -- the best of the forms in tools/copybench.hip, ~5.4 TB/s) and a read-only stream (~6.5 TB/s). */

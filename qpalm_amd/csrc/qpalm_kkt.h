@@ -38,33 +38,58 @@ QPD void kkt_form(const qpg_view &V, const QpArrays &a, int b, double *L, double
   __syncthreads();
 }
 
-/* r = b - K sol with b = [-dphi; 0] (newton.c:58-62,81-84); returns max |K sol| and max |r| */
+/* r = b - K sol with b = [-dphi; 0] (newton.c:58-62,81-84); returns max |K sol| and max |r|.
+ * The refinement loop of newton.c:64-90 stops on res <= max(1e-10 ref_norm, 1e-12), and with -1/sigma on the diagonal of a
+ * quasi-definite K the residual of a good solution is rounding noise: how many refinement passes run -- and with them the
+ * iterate -- depends on the order of the sums in mat_vec(kkt, sol).  So they are done in the REFERENCE'S order, one thread per
+ * row, no fma (this file is compiled with -ffp-contract=off):
+ *   rows 0..n-1 : the symmetric product with Q as cholmod_sdmult / ladel's symmetric mat-vec accumulate it (the entries of the
+ *                 columns before the row first, then the column's own accumulator: lob_matvec's order), then + sol/gamma
+ *                 (vec_mult_add_scaled, newton.c:59), then the entries of column j of A times the multipliers, constraint by
+ *                 constraint in ascending order (the kkt columns n+k are walked after the Q columns);
+ *   rows n+k    : the row of A times sol[0..n) in ascending column order, then the diagonal. */
 QPD void kkt_residual(const qpg_view &V, const QpArrays &a, int b, IterShared &I, double gamma, int prox, double &norm_Ksol, double &norm_r) {
   const int n = a.n, m = a.m, tid = threadIdx.x;
   const size_t sk = (size_t)V.n + V.m; /* batch strides */
   const double *sol = V.kkt_sol + (size_t)b * sk;
-  double *r = V.kkt_rhs + (size_t)b * sk, *lam = V.kkt_tmp + (size_t)b * sk;
+  double *r = V.kkt_rhs + (size_t)b * sk;
   const int *state = V.kkt_state + (size_t)b * V.m;
   __syncthreads();
-  for (int k = tid; k < m; k += QP_T) lam[k] = (state[k] == 1) ? sol[n + k] : 0.0; /* columns truncated by nz[] do not couple */
-  __syncthreads();
   const double ginv = 1.0 / gamma;
-  spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), sol, [&](int j, double s) { r[j] = prox ? (1 * s + ginv * sol[j]) : s; });
-  __syncthreads();
-  spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), lam, [&](int j, double s) { r[j] = r[j] + s; });
-  spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), sol, [&](int k, double s) {
+  double vm[2] = {0.0, 0.0}, vs[1] = {0.0};
+  for (int j = tid; j < n; j += QP_T) {
+    double up = 0.0, lo = 0.0;
+    for (int k = a.Qfp()[j]; k < a.Qfp()[j + 1]; k++) {
+      const int c = a.Qfi()[k];
+      const double t = a.Qfx()[k] * sol[c];
+      if (c < j) up += t; else lo += t;
+    }
+    double y = up + lo;
+    if (prox) y = 1 * y + ginv * sol[j];
+    for (int e = a.Ap()[j]; e < a.Ap()[j + 1]; e++) { /* rows of A in ascending order = kkt columns n+k in ascending order */
+      const int k = a.Ai()[e];
+      if (state[k] == 1) y += a.Ax()[e] * sol[n + k]; /* columns truncated by nz[] (state 0 / 2) do not couple */
+    }
+    double v = y * -1;
+    vm[0] = qmax(vm[0], qabs(v));
+    v = 1 * v + (-1) * a.dphi()[j];
+    r[j] = v;
+    vm[1] = qmax(vm[1], qabs(v));
+  }
+  for (int k = tid; k < m; k += QP_T) {
     const double xk = sol[n + k];
     const int st = state[k];
-    const bool empty = a.Atp()[k + 1] == a.Atp()[k];
-    r[n + k] = (st == 1) ? (s + (empty ? 1.0 : -a.sigma_inv()[k]) * xk) : ((st == 2) ? -a.sigma_inv()[k] * xk : xk);
-  });
-  __syncthreads();
-  double vm[2] = {0.0, 0.0}, vs[1] = {0.0};
-  for (int j = tid; j < n + m; j += QP_T) {
-    double v = r[j] * -1;
+    double y;
+    if (st == 1) {
+      double acc = 0.0;
+      const int e0 = a.Atp()[k], e1 = a.Atp()[k + 1];
+      for (int e = e0; e < e1; e++) acc += a.Atx()[e] * sol[a.Ati()[e]];
+      y = acc + ((e1 > e0) ? -a.sigma_inv()[k] : 1.0) * xk;
+    } else if (st == 2) y = -a.sigma_inv()[k] * xk;
+    else y = xk;
+    const double v = y * -1;
     vm[0] = qmax(vm[0], qabs(v));
-    if (j < n) v = 1 * v + (-1) * a.dphi()[j];
-    r[j] = v;
+    r[n + k] = v;
     vm[1] = qmax(vm[1], qabs(v));
   }
   block_reduce<2, 0>(I.S, vm, vs);

@@ -66,7 +66,7 @@ typedef struct {
   int32_t last_kind, last_fact, slot, has_scaling;
   int32_t dual_pending, kkt_first; /* kkt_first: solver->first_factorization (types.h:176), KKT path; dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
   /* work counters (device side statistics for the roofline accounting in bench.py) */
-  int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_spmv;
+  int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_fused_solve; /* n_fused_solve: Newton solves whose forward substitution rode on the last update sweep (L streamed once less) */
   int64_t ticks_total, ticks_factor, ticks_update, ticks_solve, ticks_linesearch, ticks_resid;
   int64_t ticks_dbg[QPG_NDBG]; /* [0..15] fine-grained phase timers (100 MHz ticks), see QPGStats.ms_dbg;
                                   [16..] work counters written by the linear-algebra functions themselves (QPG_CNT_*) */

@@ -28,11 +28,16 @@ def device_view(batch, name, shape, device):
     return torch.as_tensor(_DeviceArray(ptr, shape), device=device)
 
 
-def shard_indices(nqp, world, rank):
+def shard_indices(nqp, world, rank, sizes=None):
     """Round-robin assignment: per-instance cost varies by >10x inside one problem family
     (simulations/results/journal_paper/randomMPCsequential2.tex:32-61), so contiguous shards are
-    avoided; rank r owns QPs r, r + world, ..."""
-    return np.arange(rank, nqp, world)
+    avoided; rank r owns QPs r, r + world, ...  With `sizes` (one (n, m) per QP: a mixed-size batch, e.g. a directory of
+    QPS files) the round robin runs over the QPs sorted by size ("size-sorted round-robin"), so
+    that every rank gets its share of the large ones; equal sizes give the plain round robin."""
+    if sizes is None:
+        return np.arange(rank, nqp, world)
+    order = sorted(range(nqp), key=lambda k: (int(sizes[k][0]), int(sizes[k][1]), k))
+    return np.array(order[rank::world], dtype=np.int64)
 
 
 def info_matrix(batch):
@@ -48,30 +53,54 @@ def info_matrix(batch):
 pack_info = info_matrix
 
 
+def _solve_local(problems, make_batch):
+    """this rank's QPs, as size buckets when the sizes differ (members of a bucket are padded to its largest member on
+    the device only); returns per-QP x, y (own lengths) and the info rows"""
+    from .qps import bucket_by_size
+    xs, ys, infos = [None] * len(problems), [None] * len(problems), np.zeros((len(problems), len(INFO_FIELDS)))
+    uniform = len({(p.n, p.m) for p in problems}) <= 1
+    buckets = [list(range(len(problems)))] if uniform else bucket_by_size(problems)
+    for bucket in buckets:
+        if not bucket:
+            continue
+        bt = make_batch([problems[k] for k in bucket])
+        bt.solve()
+        info = pack_info(bt)
+        for pos, k in enumerate(bucket):
+            x, y = bt.solution_of(pos)
+            xs[k], ys[k], infos[k] = x.copy(), y.copy(), info[pos]
+        if hasattr(bt, "close"):
+            bt.close()
+    return xs, ys, infos
+
+
 def solve_sharded(problems, make_batch, dist=None, device=None):
     """Solve `problems` (the full list, same on every rank) sharded over the process group.
-    make_batch(list_of_problems) -> QpalmBatch.  Returns (x, y, info) on rank 0, None elsewhere."""
+    make_batch(list_of_problems) -> QpalmBatch.  Returns (x, y, info) on rank 0, None elsewhere; x is [nqp][n_max] (rows of
+    smaller members are zero-padded), y likewise."""
     import torch
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     nqp = len(problems)
-    mine = shard_indices(nqp, world, rank)
-    n, m = problems[0].n, problems[0].m
-    if len(mine):
-        bt = make_batch([problems[i] for i in mine])
-        bt.solve()
-        x, y = bt.solution()
-        info = pack_info(bt)
-    else:
-        x, y, info = np.zeros((0, n)), np.zeros((0, m)), np.zeros((0, len(INFO_FIELDS)))
-    if world == 1:
-        return x, y, info
-    # equal padded shards so that one gather moves everything (24 KB per QP at n=1000, m=2000)
+    sizes = [(int(p.n), int(p.m)) for p in problems]
+    mixed = len(set(sizes)) > 1
+    n, m = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    shard = lambda r: shard_indices(nqp, world, r, sizes if mixed else None)
+    mine = shard(rank)
     per = (nqp + world - 1) // world
+    # equal padded shards so that one gather moves everything (24 KB per QP at n=1000, m=2000)
     payload = np.zeros((per, n + m + len(INFO_FIELDS)))
-    payload[:len(mine), :n] = x
-    payload[:len(mine), n:n + m] = y
-    payload[:len(mine), n + m:] = info
+    if len(mine):
+        xs, ys, info = _solve_local([problems[i] for i in mine], make_batch)
+        for pos in range(len(mine)):
+            payload[pos, :len(xs[pos])] = xs[pos]
+            payload[pos, n:n + len(ys[pos])] = ys[pos]
+        payload[:len(mine), n + m:] = info
+    if world == 1:
+        blk = payload[:len(mine)]
+        X, Y, I = np.zeros((nqp, n)), np.zeros((nqp, m)), np.zeros((nqp, len(INFO_FIELDS)))
+        X[mine], Y[mine], I[mine] = blk[:, :n], blk[:, n:n + m], blk[:, n + m:]
+        return X, Y, I
     t = torch.from_numpy(payload)
     if device is not None:
         t = t.to(device)
@@ -81,7 +110,7 @@ def solve_sharded(problems, make_batch, dist=None, device=None):
         return None
     X, Y, I = np.zeros((nqp, n)), np.zeros((nqp, m)), np.zeros((nqp, len(INFO_FIELDS)))
     for r in range(world):
-        idx = shard_indices(nqp, world, r)
+        idx = shard(r)
         blk = bufs[r].cpu().numpy()[:len(idx)]
         X[idx], Y[idx], I[idx] = blk[:, :n], blk[:, n:n + m], blk[:, n + m:]
     return X, Y, I

@@ -69,6 +69,51 @@ static int split(char *line, char *tok[6]) {
 }
 static int is_number(const char *s) { char *e; strtod(s, &e); return e != s && *e == 0; }
 
+/* ---- the old fixed-column format (names may contain blanks).  The reference detects it by a ROWS line with a third token and
+ * first rewrites the file to "<name>_copy.qps" with the blanks squeezed out of the names (interfaces/qps/src/qps_conversion.c:36-146,
+ * called from qpalm_qps.c:104-108,731-741); here the same conversion is done line by line in memory (no file is written).  Fields
+ * by column (1-based, MPS standard): 2-3 type, 5-12 name, 15-22 name, 25-36 number, 40-47 name, 50-61 number.  The reference
+ * cuts the number fields at columns 29-37 / 53-61 (c_strcpy_limit(temp1, &line[27], 10) after one consumed character), which
+ * drops leading digits of numbers that start at column 25; this reader takes the whole field.  A Fortran 'D' exponent is
+ * accepted as 'E'.  out[] receives the squeezed fields in the order of the free format; returns their number. */
+static int field(const char *line, size_t len, size_t c0, size_t c1, char *dst) { /* columns c0..c1 (1-based, inclusive), blanks removed */
+  size_t n = 0;
+  for (size_t c = c0; c <= c1 && c <= len; c++) {
+    const char ch = line[c - 1];
+    if (ch == '\n' || ch == '\r') break;
+    if (!isspace((unsigned char)ch)) dst[n++] = ch;
+  }
+  dst[n] = 0;
+  return n > 0;
+}
+static void fortran_exponent(char *s) { for (; *s; s++) if (*s == 'D' || *s == 'd') *s = 'E'; }
+static int split_fixed(const char *line, int sec, char buf[6][40], char *tok[6]) {
+  const size_t len = strlen(line);
+  int n = 0;
+  char f1[40], f2[40], f3[40], f4[40], f5[40], f6[40];
+  const int h1 = field(line, len, 2, 3, f1), h2 = field(line, len, 5, 12, f2), h3 = field(line, len, 15, 22, f3), h4 = field(line, len, 25, 36, f4),
+            h5 = field(line, len, 40, 47, f5), h6 = field(line, len, 50, 61, f6);
+  fortran_exponent(f4); fortran_exponent(f6);
+#define QPS_PUT(f) do { snprintf(buf[n], 40, "%s", f); tok[n] = buf[n]; n++; } while (0)
+  if (sec == SEC_ROWS) {
+    if (h1) QPS_PUT(f1);
+    if (h2) QPS_PUT(f2);
+  } else if (sec == SEC_BOUNDS) {
+    if (h1) QPS_PUT(f1);
+    if (h2) QPS_PUT(f2);
+    if (h3) QPS_PUT(f3);
+    if (h4) QPS_PUT(f4);
+  }
+  else { /* COLUMNS, RHS, RANGES, QUADOBJ: name name number [name number] */
+    if (h2) QPS_PUT(f2);
+    if (h3) QPS_PUT(f3);
+    if (h4) QPS_PUT(f4);
+    if (h5 && h6) { QPS_PUT(f5); QPS_PUT(f6); }
+  }
+#undef QPS_PUT
+  return n;
+}
+
 typedef struct { long col; long row; double v; } qps_entry;
 
 int qpalm_qps_read(const char *path, QPALMData **out, char *err, size_t errlen) {
@@ -84,10 +129,13 @@ int qpalm_qps_read(const char *path, QPALMData **out, char *err, size_t errlen) 
   map_init(&rows, 64); map_init(&cols, 64); map_init(&freeb, 16);
   long m_rows = 0, n = 0, nnzA = 0, nnzQ = 0;
   char prev_col[128] = "";
-  int seen_name = 0;
+  char fbuf[6][40];
+  int seen_name = 0, fixed = 0;
+pass1:
   while (fgets(line, sizeof line, fp)) {
     lineno++;
     if (line[0] == '*' || line[0] == '\n' || line[0] == '\r') continue;
+    if (!strchr(line, '\n') && !feof(fp)) { rc = fail(err, errlen, "Line too long in %s at line %ld", path, lineno); goto done1; }
     if (!isspace((unsigned char)line[0])) { /* section header */
       char head[64] = "";
       sscanf(line, "%63s", head);
@@ -97,10 +145,19 @@ int qpalm_qps_read(const char *path, QPALMData **out, char *err, size_t errlen) 
       if (sec == SEC_END) break;
       continue;
     }
-    int nt = split(line, tok);
+    int nt = fixed ? split_fixed(line, sec, fbuf, tok) : split(line, tok);
     if (!nt) continue;
     if (sec == SEC_ROWS) {
-      if (nt != 2) { rc = fail(err, errlen, "Old fixed QPS format (names with blanks) is not supported: %s line %ld", path, lineno); goto done1; }
+      if (nt != 2) {
+        if (fixed) { rc = fail(err, errlen, "Malformed ROWS line in %s at line %ld", path, lineno); goto done1; }
+        /* a third token = a name with a blank: the old fixed-column format (qpalm_qps.c:104-108); start over by columns */
+        fixed = 1;
+        map_free(&rows); map_free(&cols); map_free(&freeb);
+        map_init(&rows, 64); map_init(&cols, 64); map_init(&freeb, 16);
+        m_rows = 0; n = 0; nnzA = 0; nnzQ = 0; prev_col[0] = 0; objective[0] = 0; seen_name = 0; sec = SEC_NONE; lineno = 0;
+        rewind(fp);
+        goto pass1;
+      }
       const char sgn = tok[0][0];
       if (sgn == 'N') { if (!objective[0]) snprintf(objective, sizeof objective, "%s", tok[1]); }
       else if (sgn == 'L' || sgn == 'G' || sgn == 'E') map_put(&rows, tok[1], m_rows++, sgn);
@@ -108,7 +165,11 @@ int qpalm_qps_read(const char *path, QPALMData **out, char *err, size_t errlen) 
     } else if (sec == SEC_COLUMNS) {
       if (nt >= 3 && !strcmp(tok[1], "'MARKER'")) { rc = fail(err, errlen, "Integrality markers are not supported (%s line %ld)", path, lineno); goto done1; }
       if (nt != 3 && nt != 5) { rc = fail(err, errlen, "Malformed COLUMNS line in %s at line %ld", path, lineno); goto done1; }
-      if (strcmp(tok[0], prev_col)) { map_put(&cols, tok[0], n++, ' '); snprintf(prev_col, sizeof prev_col, "%s", tok[0]); }
+      if (strcmp(tok[0], prev_col)) {
+        /* the entries of a column must be contiguous: a name that comes back later would be counted twice */
+        if (map_find(&cols, tok[0])) { rc = fail(err, errlen, "Column '%s' appears in two places (line %ld)", tok[0], lineno); goto done1; }
+        map_put(&cols, tok[0], n++, ' '); snprintf(prev_col, sizeof prev_col, "%s", tok[0]);
+      }
       for (int k = 1; k + 1 < nt; k += 2) if (strcmp(tok[k], objective)) nnzA++;
     } else if (sec == SEC_BOUNDS) {
       if (nt >= 2 && !strcmp(tok[0], "FR")) { const char *cname = tok[nt - 1]; if (!map_find(&freeb, cname)) map_put(&freeb, cname, 0, ' '); }
@@ -161,11 +222,12 @@ done1:
       if (sec == SEC_END) break;
       continue;
     }
-    int nt = split(line, tok);
+    int nt = fixed ? split_fixed(line, sec, fbuf, tok) : split(line, tok);
     if (!nt) continue;
     if (sec == SEC_COLUMNS) {
       const long col = map_find(&cols, tok[0])->val;
-      if (col != cur_col) { /* a new column starts: its identity (bound) entry comes FIRST (:316-324) */
+      if (col != cur_col) { /* a new column starts with its identity (bound) entry; the device layer sorts every column by row anyway
+                             * (the reference's reader leaves the columns of A unsorted) */
         cur_col = col;
         Ap[col] = elemA;
         if (brow[col] >= 0) { Ai[elemA] = brow[col]; Ax[elemA] = 1; elemA++; }
@@ -209,6 +271,11 @@ done1:
     } else if (sec == SEC_BOUNDS) {
       /* "type [setname] column [value]" */
       const char *type = tok[0];
+      if (strcmp(type, "UP") && strcmp(type, "LO") && strcmp(type, "FX") && strcmp(type, "FR") && strcmp(type, "MI") && strcmp(type, "PL")) {
+        /* BV / LI / UI (integer variables) and anything else: the reference silently keeps the default bound (qpalm_qps.c:487-495),
+         * i.e. solves another problem; refused here */
+        rc = fail(err, errlen, "Unsupported bound type '%s' at line %ld (integer bounds BV/LI/UI are not part of a QP)", type, lineno); goto done2;
+      }
       const int has_val = strcmp(type, "FR") && strcmp(type, "MI") && strcmp(type, "PL");
       const int need = has_val ? 3 : 2;
       if (nt != need && nt != need + 1) { rc = fail(err, errlen, "Malformed BOUNDS line in %s at line %ld", path, lineno); goto done2; }
@@ -225,7 +292,6 @@ done1:
       else if (!strcmp(type, "FX")) { d->bmin[br] = v; d->bmax[br] = v; }
       else if (!strcmp(type, "MI")) d->bmin[br] = -QPS_INF;
       else if (!strcmp(type, "PL")) d->bmax[br] = QPS_INF;
-      else { rc = fail(err, errlen, "Unsupported bound type '%s' at line %ld", type, lineno); goto done2; }
     } else if (sec == SEC_QUADOBJ) {
       if (nt != 3 || !is_number(tok[2])) { rc = fail(err, errlen, "Malformed QUADOBJ line in %s at line %ld", path, lineno); goto done2; }
       qps_slot *c1 = map_find(&cols, tok[0]), *c2 = map_find(&cols, tok[1]);

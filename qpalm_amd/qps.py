@@ -84,13 +84,24 @@ def bucket_by_size(problems, max_waste=0.5):
     return buckets
 
 
-def solve_qps_files(ctx, paths, settings=None, rank=0, world=1, host_lib=None):
-    """Streams QPS files as size-bucketed batches; with world > 1 every rank takes files rank, rank + world, ...
-    (sorted by size first, so that the shards are balanced).  Returns {path: (x, y, info)} for this rank's files."""
+def solve_qps_files(ctx, paths, settings=None, rank=0, world=1, host_lib=None, dist=None, device=None):
+    """BASELINE.json config 4: streams QPS files (free or old fixed format) as size-bucketed batches.
+    Without `dist`: this process is rank `rank` of `world` and takes its share of the files, sorted by size first so that
+    the shards are balanced (size-sorted round robin); returns {path: (x, y, info)} for its files.
+    With `dist` (a torch.distributed module whose process group is initialised: nccl = RCCL on the GPUs, gloo in the CPU
+    tests): the same sharding, one gather of x, y and the QPALMInfo records to rank 0, which returns
+    {path: (x, y, info_row)} for ALL files (info_row as qpalm_amd.dist.INFO_FIELDS); the other ranks return None."""
     from .solver import QpalmBatch
     probs = [read_qps(p, host_lib) for p in paths]
-    order = sorted(range(len(paths)), key=lambda k: (probs[k].n, probs[k].m))
-    mine = order[rank::world]
+    if dist is not None:
+        from .dist import solve_sharded
+        res = solve_sharded(probs, lambda ps: QpalmBatch(ctx, ps, settings), dist=dist, device=device)
+        if res is None:
+            return None
+        X, Y, I = res
+        return {paths[k]: (X[k, :probs[k].n].copy(), Y[k, :probs[k].m].copy(), I[k].copy()) for k in range(len(paths))}
+    from .dist import shard_indices
+    mine = shard_indices(len(paths), world, rank, [(p.n, p.m) for p in probs])
     out = {}
     sub = [probs[k] for k in mine]
     for bucket in bucket_by_size(sub):

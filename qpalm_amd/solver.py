@@ -96,6 +96,8 @@ class QpalmBatch:
         nnzQ = max(int(p.Qp[-1]) for p in problems)
         self.settings = settings if settings is not None else ctx.default_settings()
         h = C.c_void_p()
+        import time
+        t0 = time.perf_counter()
         self._check(self.L.qpg_batch_create(ctx.h, self.B, self.n, self.m, nnzA, nnzQ, C.byref(self.settings), C.byref(h)))
         self.h = h
         for b, p in enumerate(problems):
@@ -103,7 +105,11 @@ class QpalmBatch:
             q, bmin, bmax = f64(p.q), f64(p.bmin), f64(p.bmax)
             self._check(self.L.qpg_batch_set_problem_sized(self.h, b, int(p.n), int(p.m), iptr(Qp), iptr(Qi), fptr(Qx), iptr(Ap), iptr(Ai),
                                                            fptr(Ax), fptr(q), float(getattr(p, "c", 0.0)), fptr(bmin), fptr(bmax)))
+        t1 = time.perf_counter()
         self._check(self.L.qpg_batch_setup(self.h))
+        # what qpalm_setup does (src/qpalm.c:73-319), split as this engine does it: host-side copies / format conversion of every
+        # member (qpg_batch_set_problem), then packing + upload + the device part (Ruiz scaling, derived copies; qpg_batch_setup)
+        self.set_problem_s, self.batch_setup_s = t1 - t0, time.perf_counter() - t1
 
     def _check(self, rc):
         if rc != 0:
@@ -276,6 +282,12 @@ class QpalmBatch:
     def ldlsolve_all(self, reps=1):
         ms = C.c_float(0.0)
         self._check(self.L.qpg_batch_ldlsolve_all(self.h, int(reps), C.byref(ms)))
+        return float(ms.value)
+
+    def sweep_probe(self, reps=1, nranks=16):
+        """diagnostic: the update sweep alone on every resident workgroup (qpg_batch_sweep_probe); ms of the launch"""
+        ms = C.c_float(0.0)
+        self._check(self.L.qpg_batch_sweep_probe(self.h, int(reps), int(nranks), C.byref(ms)))
         return float(ms.value)
 
     def device_ptr(self, name):

@@ -132,10 +132,18 @@ def test_reader_errors_and_settings_file(host_lib, tmp_path):
     bad.write_text("NAME X\nROWS\n N obj\n L r1\nCOLUMNS\n    c1 r9 1.0\nENDATA\n")
     with pytest.raises(ValueError, match="Unknown row"):
         read_qps(str(bad), host_lib)
-    old = tmp_path / "old.qps"
-    old.write_text("NAME X\nROWS\n N obj name\nENDATA\n")
-    with pytest.raises(ValueError, match="Old fixed QPS format"):
-        read_qps(str(old), host_lib)
+    twice = tmp_path / "twice.qps"
+    twice.write_text("NAME X\nROWS\n N obj\n L r1\nCOLUMNS\n    c1 r1 1.0\n    c2 r1 1.0\n    c1 obj 2.0\nENDATA\n")
+    with pytest.raises(ValueError, match="appears in two places"):
+        read_qps(str(twice), host_lib)
+    intb = tmp_path / "intb.qps"
+    intb.write_text("NAME X\nROWS\n N obj\n L r1\nCOLUMNS\n    c1 r1 1.0\nBOUNDS\n BV BND c1\nENDATA\n")
+    with pytest.raises(ValueError, match="Malformed BOUNDS|Unsupported bound type"):
+        read_qps(str(intb), host_lib)
+    longl = tmp_path / "long.qps"
+    longl.write_text("NAME X\nROWS\n N obj\n L r1" + " " * 600 + "\nENDATA\n")
+    with pytest.raises(ValueError, match="Line too long"):
+        read_qps(str(longl), host_lib)
     from qpalm_amd.capi import Settings
     L = C.CDLL(host_lib)
     s = Settings()
@@ -146,6 +154,123 @@ def test_reader_errors_and_settings_file(host_lib, tmp_path):
     badset = tmp_path / "set.txt"
     badset.write_text("a\nb\nc\nd\ne\nnot_a_setting 3\n")
     assert L.qpalm_qps_read_settings(os.fsencode(str(badset)), C.byref(s), err, 256) != 0 and b"Unrecognised setting" in err.value
+
+
+def _fixed_paths():
+    return sorted(glob.glob(os.path.join(QDIR, "fixed", "fix*.qps")))
+
+
+def test_fixed_format_reader_matches_the_generated_data(host_lib):
+    """The old fixed-column format (names with blanks; the form the Maros-Meszaros files come in; the reference converts such
+    files first, interfaces/qps/src/qps_conversion.c:36-146): the 50 synthetic files of tests/golden/qps/make_fixed_qps.py against
+    the data the generator encoded in them, entry by entry (every number in the files is exact)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fixed_qps", os.path.join(QDIR, "make_fixed_qps.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    paths = _fixed_paths()
+    assert len(paths) == gen.COUNT == 50
+    blanks = 0
+    for k, path in enumerate(paths):
+        P = gen.problem(k)
+        E = gen.expected(P)
+        p = read_qps(path, host_lib)
+        assert (p.n, p.m) == (E["n"], E["m"]) and p.c == E["c"], path
+        assert np.array_equal(sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n)).toarray(), E["A"]), path
+        assert np.array_equal(sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(p.n, p.n)).toarray(), np.tril(E["Q"])), path
+        assert np.array_equal(p.q, E["q"]) and np.array_equal(p.bmin, E["bmin"]) and np.array_equal(p.bmax, E["bmax"]), path
+        blanks += P["blank"]
+    assert blanks == 40     # forty files have names with embedded blanks, ten have plain names in fixed columns
+    # the generator is deterministic: the committed files are what it writes
+    import io
+    for k in (0, 7, 49):
+        tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "fix_regen_%d_%d.qps" % (os.getpid(), k))
+        gen.write(gen.problem(k), tmp)
+        assert open(tmp).read() == open(paths[k]).read()
+        os.remove(tmp)
+
+
+def _check_against_oracle(paths, results, host_lib, st):
+    """every file of `results` {path: (x, y, info)} against the oracle on the reader's data"""
+    from qpalm_amd.dist import INFO_FIELDS
+    nsolved = 0
+    for path in paths:
+        p = read_qps(path, host_lib)
+        o = ob.OracleQP(*p.args(), c=p.c, settings=ob.default_settings(**st))
+        o.solve()
+        x, y, info = results[path]
+        if isinstance(info, np.ndarray):
+            status, it, obj = int(info[INFO_FIELDS.index("status_val")]), int(info[INFO_FIELDS.index("iter")]), float(info[INFO_FIELDS.index("objective")])
+        else:
+            status, it, obj = int(info.status_val), int(info.iter), float(info.objective)
+        assert status == o.status_val, (path, status, o.status_val)
+        assert it == int(o.info.iter), (path, it, int(o.info.iter))
+        if status == 1:
+            nsolved += 1
+            assert rel(x, o.x) <= RTOL and rel(y, o.y) <= RTOL, path
+            assert abs(obj - o.info.objective) <= 1e-9 * max(1.0, abs(o.info.objective)), path
+    return nsolved
+
+
+def _qps_rank(rank, world, port, emu_lib, host_lib, paths, st, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qpalm_amd.qps import solve_qps_files
+    from qpalm_amd.solver import Context
+    ctx = Context(0, lib_path=emu_lib)
+    res = solve_qps_files(ctx, paths, ctx.default_settings(**st), host_lib=host_lib, dist=dist)
+    if rank == 0:
+        q.put({k: (v[0], v[1], v[2]) for k, v in res.items()})
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fixed_qps_files_streamed_over_two_ranks(emu_lib, host_lib):
+    """Config 4's entry point, solve_qps_files: the 50 fixed-format files sharded over two gloo ranks (size-sorted round robin,
+    size buckets inside a shard), ONE gather to rank 0; every file against the oracle (status, iteration count, x, y, objective)."""
+    import torch.multiprocessing as mp
+    paths = _fixed_paths()
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + ((os.getpid() + 977) % 2000)
+    procs = [ctxm.Process(target=_qps_rank, args=(r, 2, port, emu_lib, host_lib, paths, st, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == sorted(paths)
+    assert _check_against_oracle(paths, res, host_lib, st) >= 30
+
+
+@pytest.mark.gpu
+def test_fixed_qps_files_on_gfx950():
+    """the same 50 files through solve_qps_files on the HIP library (host reader = the shipped libqpalm.so): as one rank, and
+    as the two shards two ranks would take, each file against the oracle"""
+    from qpalm_amd.qps import solve_qps_files
+    from qpalm_amd.solver import Context
+    ctx = Context(0)
+    assert ctx.backend == "gfx950-hip"
+    paths = _fixed_paths()
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    one = solve_qps_files(ctx, paths, ctx.default_settings(**st))
+    assert _check_against_oracle(paths, one, None, st) >= 30
+    two = {}
+    for r in range(2):
+        part = solve_qps_files(ctx, paths, ctx.default_settings(**st), rank=r, world=2)
+        assert 24 <= len(part) <= 26
+        two.update(part)
+    assert sorted(two) == sorted(paths)
+    for path in paths:
+        assert np.array_equal(one[path][0], two[path][0]) and np.array_equal(one[path][1], two[path][1])   # batch composition does not change results
 
 
 def test_qps_files_as_one_mixed_size_batch(ctx, host_lib):

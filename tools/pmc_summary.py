@@ -9,7 +9,7 @@ import sys
 
 out, repo = sys.argv[1], sys.argv[2]
 sys.path.insert(0, repo)
-from bench import source_sha256  # noqa: E402
+from bench import lib_sha256, source_sha256  # noqa: E402
 
 
 def per_launch(d, counter):
@@ -29,14 +29,15 @@ for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_A
     v, n = per_launch("pmc_sq", c)
     if v is not None:
         sq[c] = v
-batch = 8192
-try:  # the bench line of the FETCH pass names the batch it ran
+batch, n, m, kernel = 8192, 1000, 2000, "k_solve"
+try:  # the bench line of the FETCH pass names the workload it ran
     with open(os.path.join(out, "pmc_fetch_bench.json")) as f:
-        batch = int(json.load(f)["config"]["batch_per_gpu"])
+        cfg = json.load(f)["config"]
+    batch, n, m, kernel = int(cfg["batch_per_gpu"]), int(cfg.get("n", n)), int(cfg.get("m", m)), cfg.get("kernel", kernel)
 except Exception:
     pass
-res = {"kernel": "k_solve<2>", "command": "python bench.py --steps 1 --warmup 0 --no-cpu (default batch %d, n=1000, m=2000)" % batch,
-       "batch": batch, "n": 1000, "m": 2000, "source_sha256": source_sha256(),
+res = {"kernel": kernel, "command": "python bench.py --steps 1 --warmup 0 --no-cpu (batch %d, n=%d, m=%d)" % (batch, n, m),
+       "batch": batch, "n": n, "m": m, "source_sha256": source_sha256(), "lib_sha256": lib_sha256(),
        "FETCH_SIZE_KB_per_launch": fe, "WRITE_SIZE_KB_per_launch": wr, "launches_seen": [nf, nw],
        "gfx950_correction": "FETCH_SIZE x 2 (128-byte requests tallied at 64 B), WRITE_SIZE as reported",
        "traffic_bytes_per_launch": (2 * fe + wr) * 1024 if fe is not None and wr is not None else None, "sq": sq}
