@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--m", type=int, default=0, help="random workload: number of constraints (default 2 n)")
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) and run the gather of x, y and the info records even with ONE rank: "
+                         "executes the multi-GPU path's RCCL initialisation and device-view gather on a single-GPU box (tests/test_bench_launcher.py)")
     ap.add_argument("--kkt", action="store_true", help="factorization_method = FACTORIZE_KKT: the (n+m) x (n+m) KKT panel with row additions / deletions "
                                                         "(what BASELINE.json config 3 literally names) instead of the Schur panel with rank updates")
     ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
@@ -253,9 +256,12 @@ def worker(args):
         return 3
     dist = None
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from qpalm_amd.problems import random_mpc_qp, random_qp
@@ -310,7 +316,7 @@ def worker(args):
     state = {"x": None, "y": None}
 
     def gather_results():
-        if world == 1:
+        if dist is None:
             return
         from qpalm_amd.dist import device_view, info_matrix
         dev = "cuda:%d" % local
@@ -327,7 +333,8 @@ def worker(args):
                 x0 = bmin_all[:, :10] + 0.1 * rng.standard_normal((B, 10))
                 bmin_all[:, :10] = x0
                 bmax_all[:, :10] = x0
-                bt.update_bounds(bmin_all, bmax_all)
+                if bt.update_bounds(bmin_all, bmax_all) != 0:
+                    raise RuntimeError("update_bounds rejected the new bounds: " + ctx.L.qpg_last_error().decode())
                 bt.warm_start_last()      # previous solution, straight from HBM (== warm_start(*solution()), tests/test_mpc_scale.py)
             else:
                 bt.warm_start(None, None)
@@ -339,7 +346,7 @@ def worker(args):
         gather_results()
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -353,7 +360,7 @@ def worker(args):
         kernel_ms.append(bt.last_solve_ms())
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], device="cuda:%d" % local, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -429,6 +436,7 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "gathered_over": ("rccl, %d rank(s)" % world) if dist is not None else None,
             "config": {"workload": wl, "batch_per_gpu": B, "n": n, "m": m, "kernel": "k_solve<%d>" % (lambda r: 1 if r <= 1 else (2 if r <= 2 else (4 if r <= 4 else 0)))(-(-(n + (m if args.kkt else 0)) // wg_threads)),
                        "factorization": "kkt" if args.kkt else "schur", "parallelism": "batch-shard x%d" % world,
                        "update_rank_threshold": args.rank_threshold,
@@ -469,7 +477,7 @@ def worker(args):
         print(json.dumps(out))
     if not ok:
         rc = 4
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return rc

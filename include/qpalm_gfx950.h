@@ -197,6 +197,20 @@ int qpg_ldlsolveLD_neg_dphi(qpg_batch *bt, qpg_int idx);
 int qpg_compute_residuals(qpg_batch *bt, qpg_int idx);
 int qpg_set_active_constraints(qpg_batch *bt, qpg_int idx);
 int qpg_exact_linesearch(qpg_batch *bt, qpg_int idx, qpg_float *tau);
+/* ---- the KKT operations of solver_interface.h (batches created with factorization_method = FACTORIZE_KKT; QPG_ERR_UNSUPPORTED
+ * otherwise).  State as in the reference: active_constraints, enter / leave lists with nb_enter / nb_leave, sigma_inv, gamma,
+ * dphi; the (n+m) x (n+m) panel and sol_kkt / rhs_kkt live on the device ("L", "Dfac", "sol_kkt", "kkt_state"). ---- */
+/* qpalm_form_kkt / qpalm_reform_kkt (solver_interface.h:82,89; solver_interface.c:119-200): K = [[Q + I/gamma, A_a'], [A_a, -Sigma_a^-1]]
+ * for the current active set into the slot (lower triangle; inactive constraints = unit diagonal), not factorised */
+int qpg_kkt_form(qpg_batch *bt, qpg_int idx);
+/* what newton.c:36,44 calls LADEL for after (re)forming: LDL' of the matrix in the slot, natural order (ladel_factorize_*_with_diag) */
+int qpg_kkt_factorize(qpg_batch *bt, qpg_int idx);
+/* kkt_update_entering_constraints (solver_interface.h:97; .c:202-218): ladel_row_add for enter[0 .. nb_enter) */
+int qpg_kkt_update_entering_constraints(qpg_batch *bt, qpg_int idx);
+/* kkt_update_leaving_constraints (solver_interface.h:106; .c:220-236): ladel_row_del for leave[0 .. nb_leave) */
+int qpg_kkt_update_leaving_constraints(qpg_batch *bt, qpg_int idx);
+/* kkt_solve (solver_interface.h:126; .c:238-247): sol_kkt = K^-1 [-dphi; 0], d = sol_kkt[0 .. n) (no iterative refinement: that is newton.c's) */
+int qpg_kkt_solve(qpg_batch *bt, qpg_int idx);
 /* batched LDL^T solve of the current factors with right-hand side dphi (the kernel the metric's
  * "HBM GB/s on LDL" refers to): every QP of the batch, `reps` times, for benchmarking. */
 int qpg_batch_ldlsolve_all(qpg_batch *bt, qpg_int reps, float *ms_per_rep);

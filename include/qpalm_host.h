@@ -159,6 +159,17 @@ void ldlupdate_entering_constraints(QPALMWorkspace *work, solver_common *c);
 void ldldowndate_leaving_constraints(QPALMWorkspace *work, solver_common *c);
 void ldlupdate_sigma_changed(QPALMWorkspace *work, solver_common *c);
 void ldlsolveLD_neg_dphi(QPALMWorkspace *work, solver_common *c);
+/* the KKT set (solver_interface.h:82,89,97,106,126; the USE_LADEL branch of the reference): workspaces whose
+ * settings->factorization_method was FACTORIZE_KKT at qpalm_setup.  On this backend the KKT matrix is a dense (n+m) x (n+m)
+ * panel on the device, so qpalm_form_kkt / qpalm_reform_kkt both (re)build it for solver->active_constraints; the
+ * factorisation that newton.c:36,44 asks LADEL for right after them is qpalm_kkt_factorize (no reference name: LADEL's
+ * ladel_factorize_*_with_diag is called directly there).  kkt_solve fills work->d (and the device's sol_kkt). */
+void qpalm_form_kkt(QPALMWorkspace *work);
+void qpalm_reform_kkt(QPALMWorkspace *work);
+void qpalm_kkt_factorize(QPALMWorkspace *work);
+void kkt_update_entering_constraints(QPALMWorkspace *work, solver_common *c);
+void kkt_update_leaving_constraints(QPALMWorkspace *work, solver_common *c);
+void kkt_solve(QPALMWorkspace *work, solver_common *c);
 
 /* helpers for callers that built their matrices with cholmod_allocate_sparse / allocate_dense */
 solver_sparse *qpalm_sparse_alloc(size_t nrow, size_t ncol, size_t nzmax, int stype);

@@ -113,6 +113,11 @@ def _declare(L):
     L.oq_get_matrix.argtypes = [C.c_void_p, C.c_char_p, pi, pi, C.POINTER(pi), C.POINTER(pi), C.POINTER(pf)]
     L.oq_get_factor.restype = pf
     L.oq_get_factor.argtypes = [C.c_void_p, C.POINTER(pf), pi]
+    L.oq_get_kkt_factor.restype = pf
+    L.oq_get_kkt_factor.argtypes = [C.c_void_p, C.POINTER(pf), pi]
+    for f in ("oq_kkt_form_and_factor", "oq_kkt_update_entering_constraints", "oq_kkt_update_leaving_constraints", "oq_kkt_solve"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = None
     L.oq_mat_vec.argtypes = [C.POINTER(Sparse), pf, pf]
     L.oq_mat_tpose_vec.argtypes = [C.POINTER(Sparse), pf, pf]
     L.oq_mat_inf_norm_cols.argtypes = [C.POINTER(Sparse), pf]
@@ -268,6 +273,15 @@ class OracleQP:
         n = self.n
         Lm = np.ctypeslib.as_array(Lp, shape=(n * n,)).reshape(n, n).T.copy()  # column-major -> [i, j]
         return np.tril(Lm, -1) + np.eye(n), np.ctypeslib.as_array(D, shape=(n,)).copy()
+
+    def kkt_factor(self):
+        """Dense factor of the (n+m) x (n+m) KKT matrix (KKT mode): (L with unit diagonal, D)."""
+        D = C.POINTER(c_float)()
+        ld = c_int(0)
+        Lp = self.L.oq_get_kkt_factor(self.w, C.byref(D), C.byref(ld))
+        nn = int(ld.value)
+        Lm = np.ctypeslib.as_array(Lp, shape=(nn * nn,)).reshape(nn, nn).T.copy()
+        return np.tril(Lm, -1) + np.eye(nn), np.ctypeslib.as_array(D, shape=(nn,)).copy()
 
     def enable_trace(self, cap):
         n, m = self.n, self.m

@@ -1520,7 +1520,8 @@ oq_float *oq_get_vec(oq_workspace *w, const char *name, oq_int *len) {
     {"q", w->q, w->n}, {"bmin", w->bmin, w->m}, {"bmax", w->bmax, w->m}, {"D", w->D, w->n}, {"Dinv", w->Dinv, w->n},
     {"E", w->E, w->m}, {"Einv", w->Einv, w->m}, {"At_scale", w->At_scale, w->m}, {"delta_x", w->delta_x, w->n},
     {"delta_y", w->delta_y, w->m}, {"D_temp", w->D_temp, w->n}, {"E_temp", w->E_temp, w->m},
-    {"temp_m", w->temp_m, w->m}, {"temp_n", w->temp_n, w->n}, {"xx0", w->xx0, w->n}};
+    {"temp_m", w->temp_m, w->m}, {"temp_n", w->temp_n, w->n}, {"xx0", w->xx0, w->n},
+    {"sol_kkt", w->sol_kkt, w->kkt_mode ? w->n + w->m : 0}, {"rhs_kkt", w->rhs_kkt, w->kkt_mode ? w->n + w->m : 0}};
   for (size_t k = 0; k < sizeof(tab) / sizeof(tab[0]); k++)
     if (!strcmp(tab[k].nm, name)) { if (len) *len = tab[k].l; return tab[k].p; }
   if (len) *len = 0;
@@ -1587,6 +1588,28 @@ void oq_get_matrix(oq_workspace *w, const char *name, oq_int *nrow, oq_int *ncol
   if (!strcmp(name, "A")) S = &w->A; else if (!strcmp(name, "Q")) S = &w->Q; else if (!strcmp(name, "At_sqrt_sigma")) S = &w->At_sqrt_sigma;
   if (!S || !S->p) { *nrow = *ncol = 0; *p = *i = NULL; *x = NULL; return; }
   *nrow = S->nrow; *ncol = S->ncol; *p = S->p; *i = S->i; *x = S->x;
+}
+/* ---- the KKT operations of solver_interface.h:82-126 one by one (workspaces set up with FACTORIZE_KKT), for op-level tests ---- */
+void oq_kkt_form_and_factor(oq_workspace *w) { if (w->kkt_mode) { kkt_form_and_factor(w); w->first_factorization = 0; } } /* newton.c:32-45 */
+void oq_kkt_update_entering_constraints(oq_workspace *w) { /* solver_interface.c:202-218 */
+  if (w->kkt_mode) for (oq_int e = 0; e < w->nb_enter; e++) kkt_row_add(w, w->enter[e]);
+}
+void oq_kkt_update_leaving_constraints(oq_workspace *w) { /* solver_interface.c:220-236 */
+  if (w->kkt_mode) for (oq_int e = 0; e < w->nb_leave; e++) kkt_row_del(w, w->leave[e]);
+}
+void oq_kkt_solve(oq_workspace *w) { /* solver_interface.c:238-247 */
+  if (!w->kkt_mode) return;
+  const oq_int n = w->n, m = w->m, np = n + m;
+  for (oq_int j = 0; j < n; j++) w->rhs_kkt[j] = w->dphi[j] * -1;
+  for (oq_int k = 0; k < m; k++) w->rhs_kkt[n + k] = 0;
+  vec_cp(w->rhs_kkt, w->sol_kkt, (size_t)np);
+  oq_dense_ldl_solve(np, w->LDK.L, np, w->LDK.D, w->sol_kkt);
+  vec_cp(w->sol_kkt, w->d, (size_t)n);
+}
+const oq_float *oq_get_kkt_factor(const oq_workspace *w, const oq_float **D, oq_int *ld) {
+  if (D) *D = w->LDK.D;
+  if (ld) *ld = w->n + w->m;
+  return w->LDK.L;
 }
 const oq_float *oq_get_factor(const oq_workspace *w, const oq_float **D, oq_int *ld) {
   if (D) *D = w->LD.D;

@@ -108,7 +108,8 @@ def load(path=None):
     L.qpg_mat_tpose_vec.argtypes = [C.c_void_p, c_int, C.c_int, pf, pf]
     for f in ("qpg_ldlchol", "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints",
               "qpg_ldldowndate_leaving_constraints", "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi",
-              "qpg_compute_residuals", "qpg_set_active_constraints"):
+              "qpg_compute_residuals", "qpg_set_active_constraints", "qpg_kkt_form", "qpg_kkt_factorize",
+              "qpg_kkt_update_entering_constraints", "qpg_kkt_update_leaving_constraints", "qpg_kkt_solve"):
         getattr(L, f).argtypes = [C.c_void_p, c_int]
     L.qpg_exact_linesearch.argtypes = [C.c_void_p, c_int, pf]
     L.qpg_ldlchol_matrix.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pf]
@@ -135,7 +136,8 @@ SYMBOLS = [
     "qpg_batch_destroy", "qpg_batch_device_ptr", "qpg_batch_sync", "qpg_mat_vec", "qpg_mat_tpose_vec", "qpg_ldlchol",
     "qpg_ldlcholQAtsigmaA", "qpg_ldlupdate_entering_constraints", "qpg_ldldowndate_leaving_constraints",
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
-    "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_batch_sweep_probe", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
+    "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_batch_sweep_probe", "qpg_kkt_form", "qpg_kkt_factorize",
+    "qpg_kkt_update_entering_constraints", "qpg_kkt_update_leaving_constraints", "qpg_kkt_solve", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
     "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_ctx_hbm_read_gbs", "qpg_host_alloc", "qpg_host_free", "qpg_batch_set_problem_sized",
 ]
 

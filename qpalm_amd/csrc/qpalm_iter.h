@@ -862,7 +862,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
         continue;
       }
     } else if (la == 8) {
-      kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, action);
+      kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, action, I.s.nb_enter, I.s.nb_leave, QP_KKT_SOLVE | QP_KKT_REFINE);
     } else if (la == 2 || la == 4) {
       const int n_up = (la == 2) ? I.s.nb_enter : n_sig, n_dn = (la == 2) ? I.s.nb_leave : 0;
       /* a Newton step solves right after the update: its forward substitution rides on the last sweep */

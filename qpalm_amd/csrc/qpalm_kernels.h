@@ -28,6 +28,11 @@
 #define QP_OP_ACTIVE 11
 #define QP_OP_LINESEARCH 12
 #define QP_OP_FACTOR_LOADED 13
+#define QP_OP_KKT_FORM 14
+#define QP_OP_KKT_FACTOR 15
+#define QP_OP_KKT_ENTER 16
+#define QP_OP_KKT_LEAVE 17
+#define QP_OP_KKT_SOLVE 18
 
 /* qpalm_setup's device part: Ruiz scaling (scaling.c:34-113) and derived copies.
  * mode 0: fresh setup (nscale iterations); mode 1: qpalm_update_settings with more scaling
@@ -435,6 +440,12 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
     case QP_OP_RESIDUALS: dev_compute_residuals(V, a, I); break;
     case QP_OP_ACTIVE: dev_active_sets(a, I); break;
     case QP_OP_LINESEARCH: { const double tau = dev_linesearch(V, a, I, lds); if (tid == 0) I.s.tau = tau; break; }
+    /* the KKT operations of solver_interface.h:82-126 on the (n+m) x (n+m) panel (batches created with FACTORIZE_KKT) */
+    case QP_OP_KKT_FORM: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 3, 0, 0, 0); break;
+    case QP_OP_KKT_FACTOR: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 4, 0, 0, 0); break;
+    case QP_OP_KKT_ENTER: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 2, I.s.nb_enter, 0, 0); break;
+    case QP_OP_KKT_LEAVE: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 2, 0, I.s.nb_leave, 0); break;
+    case QP_OP_KKT_SOLVE: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 0, 0, 0, QP_KKT_SOLVE); break;
     default: break;
   }
   __syncthreads();

@@ -96,24 +96,28 @@ QPD void kkt_residual(const qpg_view &V, const QpArrays &a, int b, IterShared &I
   norm_Ksol = vm[0]; norm_r = vm[1];
 }
 
-/* The whole KKT branch for one Newton step.  action: 1 (re)form + factorise, 2 row additions / deletions, 0 keep. */
+/* The KKT branch.  action: 1 (re)form + factorise (qpalm_form_kkt / qpalm_reform_kkt + ladel_factorize*), 2 row additions for
+ * enter[0 .. ne) then row deletions for leave[0 .. nl) (kkt_update_entering_constraints / kkt_update_leaving_constraints),
+ * 3 form only, 4 factorise what the slot holds, 0 keep.  flags: 1 kkt_solve (solver_interface.c:238-247), 2 the iterative
+ * refinement of newton.c:57-90 on top of it.  One Newton step = (action, nb_enter, nb_leave, 3); the boundary operations of
+ * include/qpalm_gfx950.h (qpg_kkt_*) call the pieces one by one. */
+#define QP_KKT_SOLVE 1
+#define QP_KKT_REFINE 2
 template <int RPT>
-QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *Wst, IterShared *Ip, char *lds, int action_) {
+QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *Wst, IterShared *Ip, char *lds, int action_, int ne_, int nl_, int flags_) {
   const qpg_view &V = *Vp;
   IterShared &I = *Ip;
-  const int b = QP_UNIFORM(b_), action = QP_UNIFORM(action_);
+  const int b = QP_UNIFORM(b_), action = QP_UNIFORM(action_), ne = QP_UNIFORM(ne_), nl = QP_UNIFORM(nl_), flags = QP_UNIFORM(flags_);
   const QpArrays a = qp_arrays(V, b);
   const qpg_settings &st = *V.settings;
-  const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x, prox = qp_prox(st, I.s);
+  const int n = a.n, m = a.m, np = n + m, ld = V.ld, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, prox = qp_prox(st, I.s);
   const double gamma = I.s.gamma;
   const size_t sk = (size_t)V.n + V.m; /* batch strides */
   double *sol = V.kkt_sol + (size_t)b * sk, *rhs = V.kkt_rhs + (size_t)b * sk, *z = V.kkt_tmp + (size_t)b * sk;
   int *state = V.kkt_state + (size_t)b * V.m;
-  if (action == 1) {
-    kkt_form(V, a, b, L, gamma, prox);
-    dense_factor<RPT>(L, Dg, np, ld, lds, I.s.ticks_dbg);
-  } else if (action == 2) {
-    const int ne = I.s.nb_enter, nl = I.s.nb_leave;
+  if (action == 1 || action == 3) kkt_form(V, a, b, L, gamma, prox);
+  if (action == 1 || action == 4) dense_factor<RPT>(L, Dg, np, ld, lds, I.s.ticks_dbg);
+  if (action == 2) {
     for (int e = 0; e < ne + nl; e++) {
       const bool add = e < ne;
       const int k = QP_UNIFORM(add ? a.enter()[e] : a.leave()[e - ne]), p = n + k;
@@ -134,16 +138,31 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
         block_reduce<0, 1>(I.S, vm, vs);
         const double d22 = -a.sigma_inv()[k] - vs[0];
         const double sq = QP_SQRT(qabs(d22));
-        for (int i = tid; i < np; i += QP_T) { /* l32 = -(L31 z) / d22; its scaled copy is the rank-1 vector */
-          double wv = 0.0;
-          if (i > p) {
-            double acc = 0.0;
-            for (int j = 0; j < p; j++) acc = QP_FMA(L[(size_t)j * ld + i], z[j], acc);
+        /* l32 = -(L31 z) / d22; its scaled copy is the rank-1 vector.  The mat-vec is spread over the whole workgroup: blocks of
+         * 64 rows (lane = row: coalesced column segments), the p columns dealt to the wavefronts, their partial sums combined in
+         * wavefront order through LDS (one thread per row walking all p columns was a cliff for KKT panels of thousands of rows) */
+        double *part = (double *)lds; /* [QP_NW][64] */
+        for (int i = tid; i <= p && i < np; i += QP_T) Wst[i] = 0.0;
+        for (int i0 = p + 1; i0 < np; i0 += 64) {
+          const int i = i0 + lane;
+          const int ic = (i < np) ? i : np - 1;
+          double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+          int j = wid;
+          for (; j + 3 * QP_NW < p; j += 4 * QP_NW) { /* four independent column loads in flight per lane */
+            const double l0 = L[(size_t)j * ld + ic], l1 = L[(size_t)(j + QP_NW) * ld + ic], l2 = L[(size_t)(j + 2 * QP_NW) * ld + ic], l3 = L[(size_t)(j + 3 * QP_NW) * ld + ic];
+            acc0 = QP_FMA(l0, z[j], acc0); acc1 = QP_FMA(l1, z[j + QP_NW], acc1); acc2 = QP_FMA(l2, z[j + 2 * QP_NW], acc2); acc3 = QP_FMA(l3, z[j + 3 * QP_NW], acc3);
+          }
+          for (; j < p; j += QP_NW) acc0 = QP_FMA(L[(size_t)j * ld + ic], z[j], acc0);
+          __syncthreads(); /* part[] of the previous block has been consumed */
+          part[wid * 64 + lane] = (acc0 + acc1) + (acc2 + acc3);
+          __syncthreads();
+          if (wid == 0 && i < np) {
+            double acc = part[lane];
+            for (int w = 1; w < QP_NW; w++) acc += part[w * 64 + lane];
             const double l = -acc / d22;
             L[(size_t)p * ld + i] = l;
-            wv = sq * l;
+            Wst[i] = sq * l;
           }
-          Wst[i] = wv;
         }
         if (tid == 0) { Dg[p] = d22; state[k] = 1; }
         up = QP_UNIFORM((int)(d22 < 0)); /* - l32 d22 l32' */
@@ -167,12 +186,14 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
     }
     if (tid == 0) I.s.n_rank1 += ne + nl;
   }
+  if (!(flags & QP_KKT_SOLVE)) { __syncthreads(); return; }
   /* kkt_solve (solver_interface.c:238-247) */
   __syncthreads();
   for (int j = tid; j < np; j += QP_T) sol[j] = (j < n) ? a.dphi()[j] * -1 : 0.0;
   __syncthreads();
   dense_solve(L, Dg, np, ld, sol, lds, V.lds_bytes, I.s.ticks_dbg);
   for (int j = tid; j < n; j += QP_T) a.d()[j] = sol[j];
+  if (!(flags & QP_KKT_REFINE)) { __syncthreads(); return; }
   /* iterative refinement (newton.c:57-90; constants.h:101-103) */
   double nK, res;
   kkt_residual(V, a, b, I, gamma, prox, nK, res);

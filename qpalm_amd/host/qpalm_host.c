@@ -367,6 +367,23 @@ void ldlcholQAtsigmaA(QPALMWorkspace *work, solver_common *c) { (void)c; push_so
 void ldlupdate_entering_constraints(QPALMWorkspace *work, solver_common *c) { (void)c; push_solver_state(work); qpg_ldlupdate_entering_constraints(BT(work), 0); }
 void ldldowndate_leaving_constraints(QPALMWorkspace *work, solver_common *c) { (void)c; push_solver_state(work); qpg_ldldowndate_leaving_constraints(BT(work), 0); }
 void ldlupdate_sigma_changed(QPALMWorkspace *work, solver_common *c) { (void)c; push_solver_state(work); qpg_ldlupdate_sigma_changed(BT(work), 0); }
+/* ---- the KKT set (solver_interface.c:119-247), see include/qpalm_host.h ---------------------------------------------- */
+static void push_kkt_state(QPALMWorkspace *work) {
+  push_solver_state(work);
+  if (work->data->m) setv(work, "sigma_inv", work->sigma_inv, work->data->m);
+}
+void qpalm_form_kkt(QPALMWorkspace *work) { push_kkt_state(work); qpg_kkt_form(BT(work), 0); }
+void qpalm_reform_kkt(QPALMWorkspace *work) { push_kkt_state(work); qpg_kkt_form(BT(work), 0); }
+void qpalm_kkt_factorize(QPALMWorkspace *work) { qpg_kkt_factorize(BT(work), 0); }
+void kkt_update_entering_constraints(QPALMWorkspace *work, solver_common *c) { (void)c; push_kkt_state(work); qpg_kkt_update_entering_constraints(BT(work), 0); }
+void kkt_update_leaving_constraints(QPALMWorkspace *work, solver_common *c) { (void)c; push_kkt_state(work); qpg_kkt_update_leaving_constraints(BT(work), 0); }
+void kkt_solve(QPALMWorkspace *work, solver_common *c) { /* solver_interface.c:238-247: rhs = [-dphi; 0], d = sol_kkt[0 .. n) */
+  (void)c;
+  const size_t n = work->data->n;
+  setv(work, "dphi", work->dphi, n);
+  qpg_kkt_solve(BT(work), 0);
+  getv(work, "d", work->d, n);
+}
 void ldlsolveLD_neg_dphi(QPALMWorkspace *work, solver_common *c) { /* solver_interface.c:505-519; d keeps its address */
   (void)c;
   const size_t n = work->data->n;

@@ -193,8 +193,45 @@ static void suite_solver(void) {
   qpalm_cleanup(work); free_data(data);
 }
 
+/* the KKT set of solver_interface.h:82-126 through the host names (no reference test exists for them: LADEL-only, driven from
+ * newton.c).  Known answer without active constraints: K = diag(Q + I/gamma, I), so kkt_solve must reproduce test_ldlchol's
+ * d; with constraint 0 added by kkt_update_entering_constraints the solution must satisfy the Schur form of the same system,
+ * (Q + I/gamma + sigma_0 a_0 a_0') d = -dphi, and kkt_update_leaving_constraints must bring the first answer back. */
+static void suite_kkt(void) {
+  QPALMData *data = make_data(&golden_solver_interface);
+  QPALMSettings s; qpalm_set_default_settings(&s); s.eps_abs = 1e-6; s.eps_rel = 1e-6; s.verbose = 0; s.scaling = 0;
+  s.factorization_method = 0; /* FACTORIZE_KKT */
+  QPALMWorkspace *work = qpalm_setup(data, &s);
+  solver_common common, *c = &common;
+  const double TOL = 1e-8;
+  const size_t m = data->m;
+  work->settings->proximal = TRUE; work->gamma = 1e3; work->dphi[0] = -1.0; work->dphi[1] = -2.0;
+  for (size_t k = 0; k < m; k++) { work->solver->active_constraints[k] = 0; work->sigma_inv[k] = 0.5; }
+  work->solver->nb_enter = 0; work->solver->nb_leave = 0;
+  qpalm_form_kkt(work); qpalm_kkt_factorize(work); kkt_solve(work, c);
+  CHECK_NEAR(work->d[0], 3.989028924198480, TOL); CHECK_NEAR(work->d[1], 2.993017953122679, TOL);
+  /* row 0 of A = (1, 2) enters (golden_solver_interface: A = [[1,2],[3,4],[5,0]]) */
+  work->solver->active_constraints[0] = 1; work->solver->enter[0] = 0; work->solver->nb_enter = 1;
+  kkt_update_entering_constraints(work, c); kkt_solve(work, c);
+  {
+    const double a0[2] = {1.0, 2.0}, sig = 2.0, g = 1e-3;
+    const double ad = a0[0] * work->d[0] + a0[1] * work->d[1];
+    const double r0 = (1.0 + g) * work->d[0] - 1.0 * work->d[1] + sig * a0[0] * ad, r1 = -1.0 * work->d[0] + (2.0 + g) * work->d[1] + sig * a0[1] * ad;
+    CHECK_NEAR(r0, 1.0, TOL); CHECK_NEAR(r1, 2.0, TOL);
+  }
+  /* ... and leaves again; qpalm_reform_kkt + factorisation from scratch gives the same */
+  work->solver->active_constraints[0] = 0; work->solver->leave[0] = 0; work->solver->nb_enter = 0; work->solver->nb_leave = 1;
+  kkt_update_leaving_constraints(work, c); kkt_solve(work, c);
+  CHECK_NEAR(work->d[0], 3.989028924198480, TOL); CHECK_NEAR(work->d[1], 2.993017953122679, TOL);
+  work->solver->nb_leave = 0;
+  qpalm_reform_kkt(work); qpalm_kkt_factorize(work); kkt_solve(work, c);
+  CHECK_NEAR(work->d[0], 3.989028924198480, TOL); CHECK_NEAR(work->d[1], 2.993017953122679, TOL);
+  qpalm_cleanup(work); free_data(data);
+}
+
 int main(void) {
   suite_solver();
+  suite_kkt();
   for (g_verbose = 0; g_verbose < 2; g_verbose++) { /* 1 = the host-driven one-iteration-per-launch path with printing */
     suite_basic_qp();
     suite_degen_hess();

@@ -68,3 +68,28 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["solve_stats"]["all_solved"] and d["roofline"]["traffic"] is None
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["measured_copy_GBps"] > 1000
     assert set(d["roofline"]["phases"]) == {"solve", "update", "factor", "spmv_vectors"}
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_on_one_gpu():
+    """The multi-GPU path on a one-GPU box: torchrun-style environment with WORLD_SIZE = 1 and --force-dist, so that the RCCL
+    process group is really initialised and solution.x / solution.y (zero-copy device views) and the packed QPALMInfo records
+    really go through dist.gather inside the timed region.  (An 8-GPU curve cannot be measured on this pool; the N > 1 data flow
+    is covered by the two-rank gloo tests.)  Also the mpc-160 workload in KKT mode: BASELINE.json's config 3 names row
+    addition / deletion."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(_env_without_dist(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "0", "--batch", "64",
+                        "--n", "200", "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["gathered_over"] == "rccl, 1 rank(s)" and d["solve_stats"]["all_solved"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mpc-160", "--kkt", "--steps", "2", "--warmup", "1", "--batch", "256",
+                        "--no-cpu"], capture_output=True, text=True, timeout=900, env=_env_without_dist())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["factorization"] == "kkt" and d["solve_stats"]["all_solved"] and d["value"] > 0

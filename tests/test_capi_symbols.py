@@ -51,3 +51,26 @@ def test_no_gpu_fails_loudly(hip_lib):
 def test_product_loader_has_no_fallback(tmp_path):
     with pytest.raises(ImportError):
         capi.load(str(tmp_path / "missing.so"))
+
+
+def test_large_factors_get_the_lds_their_solve_needs(hip_lib):
+    """qpg_batch_create is host logic (no device memory before setup): dense_solve keeps the right-hand side behind its two 32 x 32
+    tiles in LDS, so a batch whose factor has close to 8192 rows (n + m in KKT mode) must ask for more than the default block, and
+    more than 8192 rows are refused."""
+    s = capi.Settings()
+    hip_lib.qpg_set_default_settings(C.byref(s))
+    s.factorization_method = 0          # FACTORIZE_KKT: factor rows = n + m
+    ctx = C.c_void_p(1)                 # never dereferenced before a device call... but create needs a real context:
+    # a context cannot exist without a GPU, so drive the same code through the emulated build of the same source
+    from qpalm_amd.solver import Context
+    ectx = Context(0, lib_path=build.build_emu())
+    L = ectx.L
+    for n, m, ok in ((4000, 4190, True), (1000, 2000, True), (4096, 4097, False)):
+        h = C.c_void_p()
+        rc = L.qpg_batch_create(ectx.h, 1, n, m, 10, 10, C.byref(s), C.byref(h))
+        assert (rc == 0) == ok, (n, m, rc)
+        if ok:
+            w, t, l = capi.c_int(0), capi.c_int(0), capi.c_int(0)
+            assert L.qpg_batch_launch_shape(h, C.byref(w), C.byref(t), C.byref(l)) == 0
+            assert l.value >= 2 * 32 * 33 * 8 + 256 + 8 * (n + m), (n, m, l.value)
+            L.qpg_batch_destroy(h)

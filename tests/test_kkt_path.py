@@ -134,3 +134,100 @@ def test_row_add_delete_keeps_a_valid_factor(ctx):
         if bt.num_unfinished() == 0:
             break
     assert int(bt.info(0).status_val) == STATUS["SOLVED"] and checked >= 2
+
+
+def test_boundary_kkt_operations(ctx):
+    """The five KKT entry points of solver_interface.h:82-126 one by one through the C ABI (qpg_kkt_form / _factorize /
+    _update_entering_constraints / _update_leaving_constraints / _solve), on a state taken from the middle of a solve, each
+    against the oracle's restatement of the same operation: the formed matrix against a numpy assembly, the factor entry by
+    entry after the factorisation, after the row additions and after the row deletions, and sol_kkt / d after the solve."""
+    import ctypes as C
+    n, m = sizes(ctx, (30, 50), (300, 500))
+    p = random_qp(n, m, seed=4321, density_A=max(0.02, 4.0 / n), density_M=max(0.01, 2.0 / n))
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, **KKT)
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    o = ob.OracleQP(*p.args(), settings=ob.default_settings(**dict(st, max_iter=6)))
+    o.solve()
+    bt.iterate(6)
+    for v in ("x", "y", "sigma_inv", "dphi"):
+        assert rel(bt.vec(v), o.vec(v)) <= RTOL
+    L = ob.lib()
+    ln = ob.c_int(0)
+
+    def oracle_ivec(name):
+        ptr = L.oq_get_ivec(o.w, name.encode(), C.byref(ln))
+        return np.ctypeslib.as_array(ptr, shape=(m,))
+
+    # a synthetic active set, the same on both sides; form + factorise
+    act = (np.arange(m) % 3 == 0).astype(np.int64)
+    oracle_ivec("active")[:] = act
+    bt.set_ivec("active", act)
+    np_ = n + m
+    bt.op("kkt_form")
+    # the formed matrix (lower triangle of the slot, leading dimension ld) against numpy on the device's own scaled data
+    nzA, nzQ = int(p.Ap[-1]), int(p.Qp[-1])
+    A = sp.csc_matrix((bt.named_vec("A_values", nzA), p.Ai, p.Ap), shape=(m, n)).toarray()
+    Ql = sp.csc_matrix((bt.named_vec("Q_values", nzQ), p.Qi, p.Qp), shape=(n, n)).toarray()
+    K = np.eye(np_)
+    K[:n, :n] = np.tril(Ql) + np.tril(Ql, -1).T + np.eye(n) / bt.stats(0).gamma
+    sig_inv = bt.vec("sigma_inv")
+    for k in np.where(act)[0]:
+        K[n + k, :n] = A[k]
+        K[:n, n + k] = A[k]
+        K[n + k, n + k] = -sig_inv[k] if np.any(A[k]) else 1.0
+    ld = -(-np_ // 8) * 8
+    raw = bt.named_vec("L", ld * np_).reshape(np_, ld).T[:np_]      # [i, j] = entry (i, j) of the column-major slot
+    assert np.array_equal(np.tril(raw), np.tril(K)) or np.max(np.abs(np.tril(raw) - np.tril(K))) <= 1e-15 * np.max(np.abs(K))
+    bt.op("kkt_factorize")
+    L.oq_kkt_form_and_factor(o.w)
+    Lo, Do = o.kkt_factor()
+    Lg, Dg = bt.factor_rows(np_)
+    assert rel(Dg, Do) <= 1e-10 and np.max(np.abs(np.tril(Lg, -1) - np.tril(Lo, -1))) <= 1e-10
+    # row additions for some inactive constraints, then row deletions for some active ones
+    enter = np.where(act == 0)[0][:7]
+    leave = np.where(act == 1)[0][2:7]
+    for name, lst, cnt in (("enter", enter, "nb_enter"), ("leave", leave, "nb_leave")):
+        bt.set_ivec(name, lst)
+        bt.set_scalar(cnt, len(lst))
+    act_new = act.copy(); act_new[enter] = 1; act_new[leave] = 0
+    oracle_ivec("active_old")[:] = act
+    oracle_ivec("active")[:] = act_new
+    L.oq_set_entering_leaving_constraints(o.w)
+    assert np.array_equal(o.ivec("enter"), enter) and np.array_equal(o.ivec("leave"), leave)
+    bt.set_ivec("active", act_new)
+    bt.op("kkt_update_entering_constraints")
+    L.oq_kkt_update_entering_constraints(o.w)
+    Lo, Do = o.kkt_factor()
+    Lg, Dg = bt.factor_rows(np_)
+    assert rel(Dg, Do) <= 1e-9 and np.max(np.abs(np.tril(Lg, -1) - np.tril(Lo, -1))) <= 1e-9, "after ladel_row_add"
+    bt.op("kkt_update_leaving_constraints")
+    L.oq_kkt_update_leaving_constraints(o.w)
+    Lo, Do = o.kkt_factor()
+    Lg, Dg = bt.factor_rows(np_)
+    assert rel(Dg, Do) <= 1e-9 and np.max(np.abs(np.tril(Lg, -1) - np.tril(Lo, -1))) <= 1e-9, "after ladel_row_del"
+    # the updated factor is the factor of the KKT matrix of the new active set (deleted rows: -1/sigma stays out, unit pivot)
+    K2 = np.eye(np_)
+    K2[:n, :n] = K[:n, :n]
+    for k in np.where(act_new)[0]:
+        K2[n + k, :n] = A[k]
+        K2[:n, n + k] = A[k]
+        K2[n + k, n + k] = -sig_inv[k] if np.any(A[k]) else 1.0
+    assert np.max(np.abs((Lg * Dg) @ Lg.T - K2)) <= 1e-9 * max(1.0, np.max(np.abs(K2)))
+    # kkt_solve
+    rhs = np.random.default_rng(9).standard_normal(n)
+    o.vec("dphi", copy=False)[:] = rhs
+    bt.set_vec("dphi", rhs)
+    bt.op("kkt_solve")
+    L.oq_kkt_solve(o.w)
+    assert rel(bt.vec("d"), o.vec("d")) <= 1e-9
+    sol = bt.named_vec("sol_kkt", np_)
+    assert rel(sol, o.vec("sol_kkt")) <= 1e-9
+    assert np.max(np.abs(K2 @ sol - np.concatenate([-rhs, np.zeros(m)]))) <= 1e-8 * max(1.0, np.max(np.abs(rhs)))
+
+
+def test_kkt_operations_are_refused_in_schur_mode(ctx):
+    p = random_qp(12, 20, seed=5, density_A=0.3, density_M=0.2)
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(verbose=0, factorization_method=1))
+    from qpalm_amd.capi import QpgError
+    with pytest.raises(QpgError):
+        bt.op("kkt_form")

@@ -79,6 +79,13 @@ def test_reference_infeasible(ctx, golden, name, status, k):
     bt = QpalmBatch(ctx, [fixture_qp(golden["problems"][name])], ctx.default_settings(**st))
     bt.solve()
     assert int(bt.info(0).status_val) == STATUS[status]
+    # ... in the oracle's iteration; dua_inf_qp variant 0 is the one exception: its certificate test is an equality in exact
+    # arithmetic (test_dua_inf_decision_is_a_rounding_tie proves the tie with rational arithmetic)
+    o = oracle_for(fixture_qp(golden["problems"][name]), st)
+    o.solve()
+    assert o.status_val == STATUS[status]
+    if not (name == "dua_inf_qp" and k == 0):
+        assert int(bt.info(0).iter) == int(o.info.iter), (int(bt.info(0).iter), int(o.info.iter))
 
 
 def test_reference_status_paths(ctx, golden):
