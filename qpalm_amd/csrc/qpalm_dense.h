@@ -200,8 +200,8 @@ QPN void form_schur_narrow(const qpg_view &V, int b, const int n, double *Lslot,
  * (GERSH is a run-time flag so that the kernel holds ONE copy of this loop nest.)
  * ------------------------------------------------------------------------------------------- */
 QPN double form_schur(const qpg_view &V, int b, const int n, double *Lslot, const bool GERSH, bool with_AtSA, bool proximal, double gamma,
-                      QpShared &S, char *lds) {
-  if (!GERSH && V.narrow_rows) { form_schur_narrow(V, b, n, Lslot, with_AtSA, proximal, gamma, lds); return 0.0; }
+                      QpShared &S, char *lds, const int wg = 0, const int nwg = 1) { /* (wg, nwg): this workgroup's share of the columns (k_co_form) */
+  if (!GERSH && V.narrow_rows && nwg == 1) { form_schur_narrow(V, b, n, Lslot, with_AtSA, proximal, gamma, lds); return 0.0; }
   const int ld = V.ld; /* n = this QP's dimension; the per-QP strides below are the batch's V.n / V.m */
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
@@ -217,7 +217,7 @@ QPN double form_schur(const qpg_view &V, int b, const int n, double *Lslot, cons
   double *buf = (double *)lds + (size_t)wid * n;
   double gmax = -1e300;
   __syncthreads();
-  for (int j0 = 0; j0 < n; j0 += ncb) {
+  for (int j0 = wg * ncb; j0 < n; j0 += ncb * nwg) {
     const int j = j0 + wid;
     if (wid < ncb && j < n) {
       const int lo = GERSH ? 0 : j;
@@ -816,6 +816,173 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
   }
   for (int i = tid; i < n; i += QP_T) xg[i] = xs[i];
   __syncthreads();
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * The same factorisation and triangular solves, one block column per call and the rows dealt to SEVERAL workgroups: the
+ * pieces the host chains (one launch per piece, the kernel boundary is the synchronisation) when a single large QP has
+ * the chip to itself (qpg "coop" mode, qpalm_capi.inc: coop_solve).  A batch never comes here.  Per entry the arithmetic
+ * of the factorisation and of the forward substitution is the one of dense_factor / dense_solve (k ascending, one fma
+ * per k); the backward substitution is done in outer-product form (no reduction across workgroups).
+ * ------------------------------------------------------------------------------------------- */
+/* (1) panel update of block column J for this workgroup's passes */
+QPN void co_factor_update(double *L_, double *Dg_, int n, int ld, char *lds_, int J, int wg, int nwg) {
+  const int NB = QP_FNB;
+  const bool super = (J % (2 * NB)) == 0;
+  const int k0 = super ? 0 : J - NB, k1 = J;
+  if (k1 <= k0) return;
+  const int ntiles = (n - J + 15) / 16;
+  char *stage = lds_ + ((sizeof(FactorLds) + 15) & ~(size_t)15);
+  int pass = 0;
+  for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW, pass++) {
+    if (pass % nwg != wg) continue;
+    const int rem = ntiles - tbase;
+    const int ntj = (rem + QP_NW - 1) / QP_NW;
+    if (super) {
+      if (ntj <= 1) factor_panel_update<1, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+      else factor_panel_update<2, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+    } else {
+      if (ntj <= 1) factor_panel_update<1, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+      else factor_panel_update<2, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+    }
+  }
+}
+/* (2) the 32 x 32 diagonal block (one workgroup) */
+QPN void co_factor_diag(double *L_, double *Dg_, int n, int ld, char *lds_, int J) {
+  qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_;
+  FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
+  const int NB = QP_FNB, tid = threadIdx.x, wid = tid >> 6;
+  const int jb = (n - J < NB) ? (n - J) : NB;
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += QP_T) {
+    const int c = e / NB, r = e % NB;
+    F.Ld[r][c] = (r >= c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : ((r == c) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (wid == 0) factor_diag_block(lds_);
+  __syncthreads();
+  for (int e = tid; e < jb * jb; e += QP_T) {
+    const int c = e / jb, r = e % jb;
+    if (r > c) L[(size_t)(J + c) * ld + (J + r)] = F.Ld[r][c];
+  }
+  if (tid < jb) Dg[J + tid] = F.dg[tid];
+  __syncthreads();
+}
+/* (3) rows below the block: the factorised diagonal block comes back from HBM, the rows are dealt thread by thread over the grid */
+QPN void co_factor_rows(double *L_, const double *Dg_, int n, int ld, char *lds_, int J, int wg, int nwg) {
+  qp_gdouble *L = (qp_gdouble *)L_;
+  const qp_gdouble *Dg = (const qp_gdouble *)Dg_;
+  FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
+  constexpr int NB = QP_FNB;
+  const int tid = threadIdx.x;
+  const int jb = (n - J < NB) ? (n - J) : NB;
+  if (J + jb >= n) return;
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += QP_T) {
+    const int c = e / NB, r = e % NB;
+    F.Ld[r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+  }
+  if (tid < NB) F.dv[tid] = (tid < jb) ? 1.0 / Dg[J + tid] : 1.0;
+  __syncthreads();
+  for (int i = J + jb + wg * QP_T + tid; i < n; i += QP_T * nwg) {
+    qp_gdouble *base = L + (size_t)J * ld + i;
+    double u[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) u[c] = (c < jb) ? base[(size_t)c * ld] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      if (c < jb) {
+        double v = u[c];
+#pragma unroll
+        for (int c1 = 0; c1 < c; c1++) {
+          v = QP_FMA(-u[c1], F.Ld[c][c1], v);
+          if ((c1 & 7) == 7) QP_SCHED_BARRIER();
+        }
+        u[c] = v;
+      }
+      QP_SCHED_BARRIER();
+    }
+    int ld2 = ld;
+    QP_OPAQUE(ld2);
+#pragma unroll
+    for (int c = 0; c < NB; c++)
+      if (c < jb) base[(size_t)c * ld2] = u[c] * F.dv[c];
+  }
+}
+/* forward substitution, block J: every workgroup solves the 32 x 32 block itself (cheap, and the result is needed by all), then
+ * takes its share of the rows below: x_i -= sum_c l_ic y_c, c ascending, one fma per c (dense_solve's forward arithmetic) */
+/* (the block's own result goes to xo: every workgroup reads the block of x while workgroup 0 would overwrite it) */
+QPN void co_solve_forward(const double *L_, int n, int ld, double *x_, double *xo_, char *lds_, int J, int wg, int nwg) {
+  const qp_gdouble *L = (const qp_gdouble *)L_;
+  qp_gdouble *x = (qp_gdouble *)x_, *xo = (qp_gdouble *)xo_;
+  SolveLds QP_LDS_AS &T = *QP_LDS_ARG(SolveLds, lds_);
+  const int NB = QP_SNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int jb = (n - J < NB) ? (n - J) : NB;
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += QP_T) {
+    const int c = e / NB, r = e % NB;
+    T.tile[0][r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+  }
+  __syncthreads();
+  if (wid == 0) {
+    const int ln = lane & (NB - 1);
+    double v = (lane < jb) ? x[J + lane] : 0.0;
+#pragma unroll 8
+    for (int c = 0; c < NB; c++) {
+      const double yc = qp_readlane(v, c);
+      v = QP_FMA(-T.tile[0][ln][c], yc, v);
+    }
+    if (lane < NB) T.part[lane] = v;
+    if (wg == 0 && lane < jb) xo[J + lane] = v;
+  }
+  __syncthreads();
+  for (int i = J + jb + wg * QP_T + tid; i < n; i += QP_T * nwg) {
+    double acc = x[i];
+#pragma unroll 8
+    for (int c = 0; c < NB; c++) if (c < jb) acc = QP_FMA(-L[(size_t)(J + c) * ld + i], T.part[c], acc);
+    x[i] = acc;
+  }
+}
+/* backward substitution L' x = z in outer-product form, block J (descending): every workgroup finishes x_J itself, then takes its
+ * share of the COLUMNS before the block: z_c -= sum_r l(J + r, c) x_r.  A quarter wavefront per column (32 contiguous rows of the
+ * column: two per lane), fixed reduction tree: no reduction across workgroups, results independent of the grid. */
+QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *xo_, char *lds_, int J, int wg, int nwg) {
+  const qp_gdouble *L = (const qp_gdouble *)L_;
+  qp_gdouble *x = (qp_gdouble *)x_, *xo = (qp_gdouble *)xo_;
+  SolveLds QP_LDS_AS &T = *QP_LDS_ARG(SolveLds, lds_);
+  const int NB = QP_SNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int jb = (n - J < NB) ? (n - J) : NB;
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += QP_T) {
+    const int c = e / NB, r = e % NB;
+    T.tile[0][r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+  }
+  __syncthreads();
+  if (wid == 0) { /* lane = column of the block: x_c = z_c - sum_{r > c} l_rc x_r, r descending */
+    const int ln = lane & (NB - 1);
+    double v = (lane < jb) ? x[J + lane] : 0.0;
+#pragma unroll 8
+    for (int r = NB - 1; r >= 0; r--) {
+      const double xr = qp_readlane(v, r);
+      v = QP_FMA(-T.tile[0][r][ln], xr, v); /* tile[r][c] = l(J + r, J + c), zero unless r > c */
+    }
+    if (lane < NB) T.part[lane] = (lane < jb) ? v : 0.0;
+    if (wg == 0 && lane < jb) xo[J + lane] = v;
+  }
+  __syncthreads();
+  const int grp = tid >> 4, gl = tid & 15, ngrp = QP_T / 16;
+  const double x0 = T.part[2 * gl], x1 = T.part[2 * gl + 1];
+  for (int c0 = (wg * ngrp); c0 < J; c0 += ngrp * nwg) {
+    const int c = c0 + grp;
+    double s = 0.0;
+    if (c < J) {
+      const int r0 = J + 2 * gl;
+      const double l0 = (r0 < n) ? L[(size_t)c * ld + r0] : 0.0, l1 = (r0 + 1 < n) ? L[(size_t)c * ld + r0 + 1] : 0.0;
+      s = QP_FMA(l1, x1, l0 * x0);
+    }
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (c < J && gl == 0) x[c] = x[c] - s;
+  }
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -78,8 +78,14 @@ static int rt_device_init(int device, std::string &why) {
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { why = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"; return 1; }
   return 0;
 }
-template <class K> static void rt_allow_lds(K kernel, size_t shmem) {
-  if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+#include <unordered_map>
+template <class K> static void rt_allow_lds(K kernel, size_t shmem) { /* once per kernel and size (the attribute call is not free: coop mode launches thousands of kernels) */
+  if (shmem <= 48 * 1024) return;
+  static std::unordered_map<const void *, size_t> granted;
+  size_t &g = granted[(const void *)kernel];
+  if (g >= shmem) return;
+  (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  g = shmem;
 }
 
 #define RT_BACKEND_NAME "gfx950-hip"

@@ -324,7 +324,8 @@ QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
   block_compact2(I.S, m, [&](int i) { return changed_flag[i]; }, [&](int i) { return 0; }, a.enter(), a.leave(), nchg, dummy);
   if (tid == 0) { I.s.nb_sigma_changed = nchg; I.s.n_sigma_updates++; }
   __syncthreads();
-  const double thr = qmin(st.max_rank_update_fraction * (double)(n + m), 0.25 * (double)st.max_rank_update);
+  double thr = qmin(st.max_rank_update_fraction * (double)(n + m), 0.25 * (double)st.max_rank_update);
+  if (V.offload) thr = -1.0; /* coop mode: the factor is rebuilt by many workgroups instead of updated by one (speed policy, same matrix) */
   int nupd = 0;
   if (V.kkt) {
     /* FACTORIZE_KKT (iteration.c:135-144, solver_interface.c:463-481): every branch that changes anything ends in
@@ -616,7 +617,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       I.s.dual_pending = st.enable_dual_termination ? 1 : 0;
       I.s.iter = 0; I.s.iter_out = 0; I.s.prev_iter = 0; I.s.no_change = 0;
       I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
-      I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot;
+      I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot; I.s.pend_stage = 0;
       I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
       I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0; I.s.n_fused_solve = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
@@ -638,6 +639,13 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     long long tr0 = 0;
     __syncthreads();
     const bool dual_init = (QP_UNIFORM(I.s.dual_pending) != 0); /* workgroup-uniform: keep the branch scalar */
+    const bool resume = (QP_UNIFORM(I.s.pend_stage) != 0); /* coop mode: the host has done this iteration's factorisation / solve */
+    if (resume) {
+      la = I.s.pend_la; action = I.s.pend_action; kind = I.s.pend_kind; nchange = I.s.pend_nchange; gam = I.s.pend_gam;
+      __syncthreads();
+      if (tid == 0) I.s.pend_stage = 0;
+      __syncthreads();
+    } else
     if (dual_init) la = 7;
     else {
     if (I.s.iter >= st.max_iter) { /* qpalm.c:712-735 */
@@ -848,8 +856,27 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     }
     } /* !dual_init */
     QP_OPAQUE(a.b);
+    if (V.offload && !resume && !V.kkt && (la == 1 || la == 3 || la == 7 || (kind == QP_KIND_NEWTON && la == 0))) {
+      /* coop mode: hand the factorisation (and the Newton solve that follows it) to the host's multi-workgroup kernels.  Rank
+       * updates (la == 2, 4) stay here; with the coop policy they do not occur (update_rank_threshold = 0, sigma changes reset) */
+      if (kind == QP_KIND_NEWTON && la != 7) {
+        for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1; /* ldlsolveLD_neg_dphi's right-hand side */
+      }
+      __syncthreads();
+      if (tid == 0) { I.s.pend_stage = 1; I.s.pend_la = (la == 1 || la == 3 || la == 7) ? la : 0; I.s.pend_action = action; I.s.pend_kind = kind; I.s.pend_nchange = nchange; I.s.pend_gam = gam; }
+      __syncthreads();
+      break;
+    }
     const long long t0 = QP_CLOCK();
     double gersh_ub = 0.0;
+    if (resume) {
+      if (la == 7) { /* LD_Q is ready (qpalm.c:459-468) */
+        const double dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
+        if (tid == 0) { I.s.dual_objective = dobj; I.s.dual_pending = 0; }
+        __syncthreads();
+        continue;
+      }
+    } else
     if (la == 1 || la == 3 || la == 5 || la == 7) {
       double *Lt = (la == 7) ? LQ : L, *Dt = (la == 7) ? DgQ : Dg;
       gersh_ub = form_schur(V, b, n, Lt, la == 5, la == 1 || la == 5, (la == 1 || la == 3) && (prox != 0), gam, I.S, lds);
@@ -883,7 +910,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     } else if (la == 5 || la == 6) dev_boost_gamma_apply(V, a, I, gersh_ub);
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
-      if (!V.kkt) {
+      if (!V.kkt && !resume) {
         const bool fused = (RPT > 0) && !QP_NOFUSE && (action == 2);
         if (!fused) for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
         __syncthreads();

@@ -474,6 +474,45 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_ldlsolve_all(qpg_view V, 
   }
 }
 
+/* ---- coop mode: the linear algebra of ONE QP spread over a grid of workgroups, one block column per launch (the kernel boundary is
+ * the synchronisation; chained by coop_solve in qpalm_capi.inc while the QP's iteration is suspended at its linear-algebra site).
+ * which = 0: the factor L / Dfac of the Newton system, 1: LD_Q of the dual objective.  Pieces: qpalm_dense.h (co_*). ---- */
+QPD double *co_slot_L(const qpg_view &V, int slot, int which) { return (which ? V.LQ : V.L) + (size_t)slot * V.ld * V.nfac; }
+QPD double *co_slot_D(const qpg_view &V, int slot, int which) { return (which ? V.DgQ : V.Dg) + (size_t)slot * V.nfac; }
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_form(qpg_view V, int b, int slot) {
+  __shared__ QpShared S;
+  char *lds = QP_DYN_LDS();
+  const QpArrays a = qp_arrays(V, b);
+  const qpg_scalars &sc = V.sc[b];
+  const qpg_settings &st = *V.settings;
+  const int la = sc.pend_la, prox = (st.proximal != 0 || sc.nc_flag != 0) ? 1 : 0;
+  form_schur(V, b, a.n, co_slot_L(V, slot, la == 7), false, la == 1, (la == 1 || la == 3) && prox, sc.pend_gam, S, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+/* panel update of block column J by row tiles; workgroup 0 holds the diagonal tile (pass 0) and factorises the 32 x 32 block right
+ * after it, in the same launch (nobody else reads it before the next launch) */
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_factor_update(qpg_view V, int b, int slot, int which, int J) {
+  char *lds = QP_DYN_LDS();
+  const int n = qp_arrays(V, b).n;
+  co_factor_update(co_slot_L(V, slot, which), co_slot_D(V, slot, which), n, V.ld, lds, J, (int)blockIdx.x, (int)gridDim.x);
+  if (blockIdx.x == 0) co_factor_diag(co_slot_L(V, slot, which), co_slot_D(V, slot, which), n, V.ld, lds, J);
+}
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_factor_rows(qpg_view V, int b, int slot, int which, int J) {
+  char *lds = QP_DYN_LDS();
+  co_factor_rows(co_slot_L(V, slot, which), co_slot_D(V, slot, which), qp_arrays(V, b).n, V.ld, lds, J, (int)blockIdx.x, (int)gridDim.x);
+}
+/* ldlsolveLD_neg_dphi on d (the suspended iteration wrote -dphi there): phase 0 forward block J (solved blocks collect in temp_n),
+ * 1 division by D back into d, 2 backward block J (solved blocks collect in temp_n), 3 d <- temp_n */
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_solve(qpg_view V, int b, int slot, int phase, int J) {
+  char *lds = QP_DYN_LDS();
+  const QpArrays a = qp_arrays(V, b);
+  const int n = a.n;
+  double *L = co_slot_L(V, slot, 0), *Dg = co_slot_D(V, slot, 0);
+  if (phase == 0) co_solve_forward(L, n, V.ld, a.d(), a.temp_n(), lds, J, (int)blockIdx.x, (int)gridDim.x);
+  else if (phase == 1) { for (int i = blockIdx.x * QP_T + threadIdx.x; i < n; i += QP_T * gridDim.x) a.d()[i] = a.temp_n()[i] / Dg[i]; }
+  else if (phase == 2) co_solve_backward(L, n, V.ld, a.d(), a.temp_n(), lds, J, (int)blockIdx.x, (int)gridDim.x);
+  else { for (int i = blockIdx.x * QP_T + threadIdx.x; i < n; i += QP_T * gridDim.x) a.d()[i] = a.temp_n()[i]; }
+}
+
 /* Diagnostic (tools/sweep_probe.py): every resident workgroup factorises Q + I/gamma of its QP and then applies `reps` times a
  * rank-`nranks` update followed by the downdate with the same rows of A (constraints 0 .. nranks-1), so that variants of the
  * update sweep can be timed under the contention of a full chip without running the solver around them.  The phase timers of

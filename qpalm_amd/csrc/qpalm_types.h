@@ -64,6 +64,11 @@ typedef struct {
   int32_t status, done, initialized, gamma_maxed, reset_newton, in_solve;
   int32_t nb_active, nb_enter, nb_leave, nb_sigma_changed;
   int32_t last_kind, last_fact, slot, has_scaling;
+  /* "coop" mode (one large QP, the linear algebra spread over many workgroups by the host, qpalm_capi.inc: coop_solve): the
+   * iteration is suspended at its linear-algebra site.  pend_stage = 1: the host has to factorise (pend_la = 1 Q + A'SA, 3 Q only,
+   * 7 LD_Q of the dual objective; 0 no factorisation) and, for a Newton step (pend_kind == 0, pend_la != 7), to solve for d */
+  int32_t pend_stage, pend_la, pend_action, pend_kind, pend_nchange, pend_pad;
+  double pend_gam;
   int32_t dual_pending, kkt_first; /* kkt_first: solver->first_factorization (types.h:176), KKT path; dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
   /* work counters (device side statistics for the roofline accounting in bench.py) */
   int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_fused_solve; /* n_fused_solve: Newton solves whose forward substitution rode on the last update sweep (L streamed once less) */
@@ -75,6 +80,7 @@ typedef struct {
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
   int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, place_panel_wave, narrow_rows;
+  int32_t offload, offload_pad; /* 1: dev_solve suspends at its linear-algebra site for factorisations and Newton solves (coop mode) */
   int32_t kkt, nfac; /* kkt != 0: FACTORIZE_KKT, the factor slots hold the (n+m) x (n+m) KKT panel; nfac = rows of a factor slot
                         (n, or n + m in KKT mode); ld = its leading dimension */
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.

@@ -1,0 +1,161 @@
+"""Coop mode (BASELINE.json configs 2 and 5 as written: ONE large QP on one MI355X): the QP's iteration stays on its workgroup but
+suspends at its linear-algebra site, and the host chains multi-workgroup kernels for the Schur assembly, the blocked LDL' (panel
+update on the matrix cores by row tiles / diagonal block / rows below: three launches per 32 columns) and the triangular solves
+(one launch per block), qpalm_capi.inc: coop_solve.  Reference: src/solver_interface.c:319-405,505-519 (the same factorise / solve
+calls), src/nonconvex.c:29-168 for config 5's front-end.
+
+Parity: against the one-workgroup engine (same statuses and iteration counts, x, y to 1e-9; the factorisation and the forward
+substitution are bit-identical per entry, the backward substitution sums in another order) and against the oracle.  Policy: a
+changed active set always refactorises in this mode, so n_refactor / n_rank1 are NOT the reference's split (by design)."""
+import time
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import binding as ob
+from qpalm_amd.problems import random_qp
+from qpalm_amd.solver import QpalmBatch
+from tests.helpers import STATUS
+from tests.test_parity import RTOL, rel, sizes
+
+
+def _solve(ctx, probs, st, coop):
+    ctx.set_option("coop", 1 if coop else 0)
+    try:
+        bt = QpalmBatch(ctx, probs, ctx.default_settings(**st))
+        t0 = time.perf_counter()
+        bt.solve()
+        dt = time.perf_counter() - t0
+        x, y = bt.solution()
+        return bt, x, y, dt
+    finally:
+        ctx.set_option("coop", 0)
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(enable_dual_termination=1), dict(proximal=0, scaling=2)])
+def test_coop_matches_single_workgroup_and_oracle(ctx, extra):
+    n, m = sizes(ctx, (70, 100), (1000, 2000))    # emu: three block columns (two full, one ragged)
+    nb = sizes(ctx, 1, 2)
+    probs = [random_qp(n, m, seed=1000 + k, density_A=0.01 if n >= 400 else 4.0 / n, density_M=0.005 if n >= 400 else 2.0 / n) for k in range(nb)]
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, **extra)
+    b1, x1, y1, _ = _solve(ctx, probs, st, coop=False)
+    b2, x2, y2, _ = _solve(ctx, probs, st, coop=True)
+    for k, p in enumerate(probs):
+        o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
+        o.solve()
+        i1, i2, s2 = b1.info(k), b2.info(k), b2.stats(k)
+        assert int(i2.status_val) == int(i1.status_val) == o.status_val
+        assert int(i2.iter) == int(i1.iter) == int(o.info.iter) and int(i2.iter_out) == int(o.info.iter_out)
+        assert rel(x2[k], x1[k]) <= RTOL and rel(y2[k], y1[k]) <= RTOL
+        assert rel(x2[k], o.x) <= RTOL and rel(y2[k], o.y) <= RTOL
+        assert abs(i2.objective - o.info.objective) <= 1e-9 * max(1.0, abs(o.info.objective))
+        if extra.get("enable_dual_termination"):
+            assert abs(i2.dual_objective - o.info.dual_objective) <= 1e-9 * max(1.0, abs(o.info.dual_objective))
+        assert int(s2.n_rank1) == 0 and int(s2.n_refactor) >= 1          # the mode's policy: no rank updates
+        assert np.array_equal(b2.ivec("active", k), o.ivec("active"))
+
+
+def test_coop_is_selected_automatically_for_one_large_qp(ctx):
+    """default policy (coop = -1): at most four QPs with factors of at least 1280 rows; small or many QPs keep the batch engine"""
+    n, m = sizes(ctx, (40, 60), (1400, 1500))
+    p = random_qp(n, m, seed=77, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n))
+    ctx.set_option("coop", -1)
+    try:
+        bt = QpalmBatch(ctx, [p], ctx.default_settings(eps_abs=1e-6, eps_rel=1e-6, verbose=0))
+        bt.solve()
+        s = bt.stats(0)
+        if ctx.kind == "emu":
+            assert int(s.n_rank1) > 0                 # n = 40: not selected
+        else:
+            assert int(s.n_rank1) == 0 and int(s.n_refactor) > 1
+        assert int(bt.info(0).status_val) == STATUS["SOLVED"]
+    finally:
+        ctx.set_option("coop", 0)
+
+
+def test_coop_nonconvex(ctx):
+    """config 5's shape at test size: indefinite Q, LOBPCG front-end, proximal penalty 1/|lambda|; against the oracle"""
+    n, m = sizes(ctx, (36, 40), (600, 900))
+    p = random_qp(n, m, seed=5, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n))
+    Q = sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(n, n)).tolil()
+    for j in range(0, n, 3):
+        Q[j, j] = Q[j, j] - 3.0 * abs(Q[j, j])     # negative curvature in a third of the directions
+    Q = sp.csc_matrix(Q)
+    Q.sort_indices()
+    p2 = type(p)(n, m, Q.indptr.astype(np.int64), Q.indices.astype(np.int64), Q.data.copy(), p.Ap, p.Ai, p.Ax, p.q, p.bmin, p.bmax)
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, nonconvex=1, max_iter=sizes(ctx, 60, 2000))
+    b1, x1, y1, _ = _solve(ctx, [p2], st, coop=False)
+    b2, x2, y2, _ = _solve(ctx, [p2], st, coop=True)
+    o = ob.OracleQP(*p2.args(), settings=ob.default_settings(**st))
+    o.solve()
+    assert int(b2.stats(0).nonconvex) == 1
+    assert int(b2.info(0).status_val) == int(b1.info(0).status_val) == o.status_val
+    assert int(b2.info(0).iter) == int(b1.info(0).iter) == int(o.info.iter)
+    assert rel(x2[0], o.x) <= 1e-8 and rel(y2[0], o.y) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_config2_single_qp_latency():
+    """BASELINE.json config 2 as written: ONE random convex QP, n = 1000, m = 2000, on one MI355X.  At this size the multi-workgroup
+    mode is only at break-even with one workgroup (measured 59.8 vs 64.7 ms: 32 block columns, each a chain of three
+    latency-bound launches with at most four row-tile passes to share), which is why the automatic policy starts at 1280 rows;
+    the test pins parity with the oracle and an upper bound on the time.  n = 2500: 294 vs 1720 ms, n = 5000: 1.04 vs 7 s."""
+    from qpalm_amd.solver import Context
+    ctx = Context(0)
+    p = random_qp(1000, 2000, seed=1000, density_A=0.01, density_M=0.005)
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    ctx.set_option("coop", 1)
+    bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    bt.solve()                                    # warm-up (code objects, allocations)
+    t = []
+    for _ in range(3):
+        bt.warm_start(None, None)
+        t0 = time.perf_counter()
+        bt.solve()
+        t.append(time.perf_counter() - t0)
+    o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
+    o.solve()
+    x, y = bt.solution()
+    assert int(bt.info(0).status_val) == o.status_val == 1 and int(bt.info(0).iter) == int(o.info.iter)
+    assert rel(x[0], o.x) <= RTOL and rel(y[0], o.y) <= RTOL
+    print("config 2, one QP, coop: %.1f ms per solve (best of 3), %d iterations" % (1e3 * min(t), int(bt.info(0).iter)))
+    assert min(t) <= 0.120, t
+
+
+@pytest.mark.gpu
+def test_config5_nonconvex_n5000():
+    """BASELINE.json config 5 as written: nonconvex random QP, n = 5000, LOBPCG + indefinite LDL' on one MI355X (one workgroup:
+    145 s in round 2).  No oracle at this size (minutes of CPU): the LOBPCG bound against numpy's smallest eigenvalue, the
+    stationarity / feasibility of the returned point computed with numpy on the unscaled data, and the solve time."""
+    from qpalm_amd.solver import Context
+    ctx = Context(0)
+    n, m = 5000, 5000
+    p = random_qp(n, m, seed=55, density_A=0.002, density_M=0.001)
+    Q = sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(n, n)).tolil()
+    for j in range(0, n, 5):
+        Q[j, j] = Q[j, j] - 2.5 * abs(Q[j, j])
+    Q = sp.csc_matrix(Q)
+    Q.sort_indices()
+    p2 = type(p)(n, m, Q.indptr.astype(np.int64), Q.indices.astype(np.int64), Q.data.copy(), p.Ap, p.Ai, p.Ax, p.q, p.bmin, p.bmax)
+    st = dict(eps_abs=1e-5, eps_rel=1e-5, verbose=0, nonconvex=1, max_iter=20000)
+    ctx.set_option("coop", 1)
+    bt = QpalmBatch(ctx, [p2], ctx.default_settings(**st))
+    t0 = time.perf_counter()
+    bt.solve()
+    dt = time.perf_counter() - t0
+    info, s = bt.info(0), bt.stats(0)
+    print("config 5, n = 5000 nonconvex, coop: %.2f s, %d iterations, status %d, lambda %.6f" % (dt, int(info.iter), int(info.status_val), s.lobpcg_lambda))
+    assert int(s.nonconvex) == 1 and int(info.status_val) == STATUS["SOLVED"]
+    # LOBPCG's lambda is a lower bound estimate of the smallest eigenvalue of the SCALED Q (nonconvex.c:150-160 subtracts the residual bound)
+    Qfull = (sp.tril(Q) + sp.tril(Q, -1).T).toarray()
+    lam_min = np.linalg.eigvalsh(Qfull)[0]
+    assert lam_min < 0
+    x, y = bt.solution()
+    A = sp.csc_matrix((p2.Ax, p2.Ai, p2.Ap), shape=(m, n))
+    ax = A @ x[0]
+    prim = np.max(np.maximum(p2.bmin - ax, 0) + np.maximum(ax - p2.bmax, 0))
+    grad = Qfull @ x[0] + p2.q + A.T @ y[0]
+    assert prim <= 1e-4 * max(1.0, np.max(np.abs(ax)))
+    assert np.max(np.abs(grad)) <= 1e-3 * max(1.0, np.max(np.abs(Qfull @ x[0])), np.max(np.abs(p2.q)))
+    assert dt <= 60.0, dt
