@@ -38,9 +38,35 @@ def build_hip(force=False, verbose=False):
     cmd += os.environ.get("QPALM_EXTRA_DEFS", "").split()  # experiments: e.g. -DQP_UHELP=1
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # -save-temps into a scratch directory: the device assembly is checked for a ROCm 7.2 register-allocator fault
+    # (tools/scan_exec_prologue.py: register copies ahead of an exec restore; round 3's wrong dual objective on the GPU)
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="qpalm_build_")
+    try:
+        subprocess.check_call(cmd + ["-save-temps"], cwd=tmp)
+        asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
+        if not asm:
+            raise RuntimeError("hipcc -save-temps left no gfx950 assembly in %s" % tmp)
+        check_device_assembly(os.path.join(tmp, asm[0]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     build_host()
     return LIB
+
+
+def check_device_assembly(path):
+    """Fails the build when the device assembly holds a VGPR-to-VGPR copy ahead of the `s_or_b64 exec` of its block."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_exec_prologue", os.path.join(ROOT, "tools", "scan_exec_prologue.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.copies(mod.scan(path))
+    if bad:
+        if os.path.exists(LIB):
+            os.remove(LIB)
+        raise RuntimeError("register copies ahead of an exec restore (compiler fault, see tools/scan_exec_prologue.py):\n" +
+                           "\n".join("%s %s line %d: %s" % b for b in bad[:20]))
 
 
 def build_host():

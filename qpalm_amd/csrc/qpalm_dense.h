@@ -825,25 +825,24 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
  * of the factorisation and of the forward substitution is the one of dense_factor / dense_solve (k ascending, one fma
  * per k); the backward substitution is done in outer-product form (no reduction across workgroups).
  * ------------------------------------------------------------------------------------------- */
-/* (1) panel update of block column J for this workgroup's passes */
-QPN void co_factor_update(double *L_, double *Dg_, int n, int ld, char *lds_, int J, int wg, int nwg) {
+/* (1) right-looking trailing update after block column J (32 finished columns k = J .. J+31): every later block column Jc gets
+ * P(Jc:n, Jc:Jc+32) -= L(Jc:n, k) D(k) L(Jc:Jc+32, k)' for those 32 k, the (block column, row pass) items dealt round-robin to the
+ * workgroups.  The same MFMA routine as dense_factor's left-looking update, called with a 32-wide k range: an entry receives
+ * its k terms in ascending order, four per MFMA, exactly as there (stores and loads between the blocks are lossless), so the
+ * factor is bit-identical -- but nothing here waits on a chain of J / 32 staged chunks, and all workgroups have work. */
+QPN void co_factor_trailing(double *L_, double *Dg_, int n, int ld, char *lds_, int J, int wg, int nwg) {
   const int NB = QP_FNB;
-  const bool super = (J % (2 * NB)) == 0;
-  const int k0 = super ? 0 : J - NB, k1 = J;
-  if (k1 <= k0) return;
-  const int ntiles = (n - J + 15) / 16;
+  if (J + NB >= n) return;
   char *stage = lds_ + ((sizeof(FactorLds) + 15) & ~(size_t)15);
-  int pass = 0;
-  for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW, pass++) {
-    if (pass % nwg != wg) continue;
-    const int rem = ntiles - tbase;
-    const int ntj = (rem + QP_NW - 1) / QP_NW;
-    if (super) {
-      if (ntj <= 1) factor_panel_update<1, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
-      else factor_panel_update<2, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
-    } else {
-      if (ntj <= 1) factor_panel_update<1, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
-      else factor_panel_update<2, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+  int item = 0;
+  for (int Jc = J + NB; Jc < n; Jc += NB) {
+    const int ntiles = (n - Jc + 15) / 16;
+    for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW, item++) {
+      if (item % nwg != wg) continue;
+      const int rem = ntiles - tbase;
+      const int ntj = (rem + QP_NW - 1) / QP_NW;
+      if (ntj <= 1) factor_panel_update<1, 2>(L_, Dg_, stage, n, ld, Jc, tbase, J, J + NB);
+      else factor_panel_update<2, 2>(L_, Dg_, stage, n, ld, Jc, tbase, J, J + NB);
     }
   }
 }
@@ -1950,6 +1949,51 @@ struct UpdownBigLds {
   double Wt[K];
   double dd[QP_UNB];
 };
+/* the recurrence on one 32 x 32 diagonal block (in U.Ld / dreg, lane = row of the block) for kk <= K ranks: leaves the table
+ * (-w_j, -gamma) of the block's columns in U.cwg, the new entries in U.Ld and the new pivots in dreg; lane r carries alpha_r */
+template <int K>
+QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const int jb, const int kk, const double sg,
+                          double (&wrow)[K], double &dreg, double &alpha, double &ialpha) {
+#pragma unroll 1
+  for (int c1 = 0; c1 < jb; c1++) {
+    const int ln = QP_FRESH_LANE(lane);
+    const double lcur = (ln > c1 && ln < jb) ? U.Ld[ln][c1] : 0.0;
+    if (ln == c1) {
+#pragma unroll
+      for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
+    }
+    QP_WAVE_SYNC();
+    const double wv = (ln < kk) ? U.Wt[ln & (K - 1)] : 0.0;
+    const double d0 = qp_readlane(dreg, c1);
+    const double p = sg * wv * wv * ialpha;
+    double incl = p;
+    if (K > 1) incl += qp_row_shr<1>(incl);
+    if (K > 2) incl += qp_row_shr<2>(incl);
+    if (K > 4) incl += qp_row_shr<4>(incl);
+    if (K > 8) incl += qp_row_shr<8>(incl);
+    const double excl = qp_row_shr<1>(incl);
+    const double dnew = d0 + incl, dprev = d0 + excl;
+    const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
+    const double gam = -sg * wv * ialpha * rdn;
+    if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; }
+    alpha = alpha * dnew * rdp;
+    ialpha = ialpha * dprev * rdn;
+    { const double dfin = qp_readlane(dnew, kk - 1); if (ln == c1) dreg = dfin; }
+    QP_WAVE_SYNC();
+    {
+      double l = lcur;
+#pragma unroll
+      for (int r = 0; r < K; r++) {
+        if (r >= kk) break;
+        wrow[r] = QP_FMA(U.cwg[c1][r][0], l, wrow[r]);
+        l = QP_FMA(U.cwg[c1][r][1], wrow[r], l);
+      }
+      if (ln > c1 && ln < jb) U.Ld[ln][c1] = l;
+    }
+    QP_SCHED_BARRIER();
+  }
+}
+
 template <int K>
 QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_, const int n_, const int ld_,
                            double *L_, double *Dg_, double *Wst_, const int *cols_, int n_up_,
@@ -2006,44 +2050,7 @@ QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb && r < kk) ? Wst[(size_t)r * n + J + lane] : 0.0;
         double dreg = (lane < jb) ? U.dd[lane] : 1.0;
-#pragma unroll 1
-        for (int c1 = 0; c1 < jb; c1++) {
-          const int ln = QP_FRESH_LANE(lane);
-          const double lcur = (ln > c1 && ln < jb) ? U.Ld[ln][c1] : 0.0;
-          if (ln == c1) {
-#pragma unroll
-            for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
-          }
-          QP_WAVE_SYNC();
-          const double wv = (ln < kk) ? U.Wt[ln & (K - 1)] : 0.0;
-          const double d0 = qp_readlane(dreg, c1);
-          const double p = sg * wv * wv * ialpha;
-          double incl = p;
-          if (K > 1) incl += qp_row_shr<1>(incl);
-          if (K > 2) incl += qp_row_shr<2>(incl);
-          if (K > 4) incl += qp_row_shr<4>(incl);
-          if (K > 8) incl += qp_row_shr<8>(incl);
-          const double excl = qp_row_shr<1>(incl);
-          const double dnew = d0 + incl, dprev = d0 + excl;
-          const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
-          const double gam = -sg * wv * ialpha * rdn;
-          if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; }
-          alpha = alpha * dnew * rdp;
-          ialpha = ialpha * dprev * rdn;
-          { const double dfin = qp_readlane(dnew, kk - 1); if (ln == c1) dreg = dfin; }
-          QP_WAVE_SYNC();
-          {
-            double l = lcur;
-#pragma unroll
-            for (int r = 0; r < K; r++) {
-              if (r >= kk) break;
-              wrow[r] = QP_FMA(U.cwg[c1][r][0], l, wrow[r]);
-              l = QP_FMA(U.cwg[c1][r][1], wrow[r], l);
-            }
-            if (ln > c1 && ln < jb) U.Ld[ln][c1] = l;
-          }
-          QP_SCHED_BARRIER();
-        }
+        updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha);
         if (lane < jb) Dg[J + lane] = dreg;
 #pragma unroll 1
         for (int c = 0; c < jb; c++)
@@ -2073,6 +2080,123 @@ QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[7] += tq1 - tq0; tq0 = tq1; }
   }
   __syncthreads();
+}
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Coop mode (one large QP on many workgroups, qpalm_capi.inc: coop_linear_algebra): the multi-rank update of dense_updown_big
+ * with ONE LAUNCH PER BLOCK COLUMN.  Every workgroup repeats the recurrence on the 32 x 32 diagonal block (a few microseconds)
+ * from the same inputs and then applies the table to its share of the rows below; the kernel boundary orders block J + 1
+ * after block J.  Workgroup 0 owns the block's outputs: the new diagonal block and pivots go to a stage (the other workgroups
+ * may still be reading the old ones) and are written into L / D by the NEXT launch; the running alpha_r alternate between two
+ * buffers.  State of one update, in the slot's stash area of Wst (hst = Wst + K n + QPG_DUMMY):
+ *   hst[0..4K)  alpha, 1/alpha: buffer (J / 32) & 1 is read, the other written      hst[CO_UD_JMIN] first nonzero row
+ *   hst[CO_UD_STAGED] block column held by the stage (-1 none)    hst[CO_UD_D ..) 32 pivots    hst[CO_UD_L ..) 32 x 32 entries
+ * The arithmetic per entry is dense_updown_big's, so the factor is bit-identical to the one-workgroup sweep's.
+ * ------------------------------------------------------------------------------------------- */
+#define CO_UD_JMIN 100
+#define CO_UD_STAGED 101
+#define CO_UD_D 128
+#define CO_UD_L 160
+#define CO_UD_ROWS 128 /* rows of the panel per workgroup and pass */
+/* phase 0 (all workgroups): Wst <- 0; phase 1 (one workgroup): the kk sparse rows of sqrt(Sigma) A scattered into it, state initialised */
+template <int K>
+QPD void co_updown_init(const int *Atp, const int *Ati, const double *Atss, const int n, double *Wst, double *hst, const int *cols, const int n_up,
+                        const int *cols_dn, const int r0, const int kk, const int phase, QpShared &S, const int wg, const int nwg) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (phase == 0) {
+    for (size_t e = (size_t)wg * QP_T + tid; e < (size_t)kk * n; e += (size_t)nwg * QP_T) Wst[e] = 0.0;
+    return;
+  }
+  int jmin = n;
+  for (int r = wid; r < kk; r += QP_NW) {
+    const int g = r0 + r;
+    const int t = (g < n_up) ? cols[g] : cols_dn[g - n_up];
+    for (int k = Atp[t] + lane; k < Atp[t + 1]; k += 64) {
+      const int i = Ati[k];
+      Wst[(size_t)r * n + i] = Atss[k];
+      jmin = (i < jmin) ? i : jmin;
+    }
+  }
+  jmin = block_imin(S, jmin);
+  if (tid < 4 * K) hst[tid] = 1.0;
+  if (tid == 0) { hst[CO_UD_JMIN] = (double)((jmin < n) ? jmin : n - 1); hst[CO_UD_STAGED] = -1.0; }
+}
+/* block column J (J >= n: only the pending stage is written back) */
+template <int K>
+QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, double *Wst, double *hst, const int J, const int r0, const int kk,
+                         const int n_up, char *lds, const int wg, const int nwg) {
+  typedef UpdownBigLds<K> LdsT;
+  LdsT QP_LDS_AS &U = *QP_LDS_ARG(LdsT, lds);
+  const int NB = QP_UNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (J < n && J + NB <= (int)hst[CO_UD_JMIN]) return; /* the update vectors are zero above their first entry */
+  if (wg == 0) { /* the previous block's outputs, staged by workgroup 0 of the previous launch */
+    const int Js = (int)hst[CO_UD_STAGED];
+    if (Js >= 0) {
+      const int js = (n - Js < NB) ? (n - Js) : NB;
+      for (int e = tid; e < js * js; e += QP_T) {
+        const int c1 = e / js, c = e % js;
+        if (c > c1) L[(size_t)(Js + c1) * ld + (Js + c)] = hst[CO_UD_L + c1 * NB + c];
+      }
+      if (tid < js) Dg[Js + tid] = hst[CO_UD_D + tid];
+    }
+    __syncthreads();
+    if (tid == 0) hst[CO_UD_STAGED] = -1.0;
+  }
+  if (J >= n) return;
+  const int jb = (n - J < NB) ? (n - J) : NB, par = (J / NB) & 1;
+  for (int e = tid; e < jb * jb; e += QP_T) { /* diagonal block to LDS */
+    const int c1 = e / jb, c = e % jb;
+    if (c > c1) U.Ld[c][c1] = L[(size_t)(J + c1) * ld + (J + c)];
+  }
+  if (tid < jb) U.dd[tid] = Dg[J + tid];
+  __syncthreads();
+  if (wid == 0) {
+    double wrow[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) wrow[r] = (lane < jb && r < kk) ? Wst[(size_t)r * n + J + lane] : 0.0;
+    double dreg = (lane < jb) ? U.dd[lane] : 1.0;
+    double alpha = (lane < K) ? hst[par * 2 * K + lane] : 1.0, ialpha = (lane < K) ? hst[par * 2 * K + K + lane] : 1.0;
+    const int grank = r0 + lane;
+    const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
+    updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha);
+    if (wg == 0) {
+      if (lane < K) { hst[(1 - par) * 2 * K + lane] = alpha; hst[(1 - par) * 2 * K + K + lane] = ialpha; }
+      if (lane < jb) hst[CO_UD_D + lane] = dreg;
+#pragma unroll 1
+      for (int c = 0; c < jb; c++)
+        if (lane > c && lane < jb) hst[CO_UD_L + c * NB + lane] = U.Ld[lane][c];
+      if (lane == 0) hst[CO_UD_STAGED] = (double)J;
+    }
+  }
+  __syncthreads();
+  /* rows below the block (full blocks only: the last, ragged block has none): one row per thread, its kk running values from / to
+   * HBM, the 32 entries of the row in two batches of 16 loads */
+  if (tid < CO_UD_ROWS)
+    for (int i = J + NB + wg * CO_UD_ROWS + tid; i < n; i += nwg * CO_UD_ROWS) {
+      double w[K];
+#pragma unroll
+      for (int r = 0; r < K; r++) w[r] = (r < kk) ? Wst[(size_t)r * n + i] : 0.0;
+#pragma unroll 1
+      for (int h = 0; h < NB; h += 16) {
+        double l[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) l[c] = L[(size_t)(J + h + c) * ld + i];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+#pragma unroll
+          for (int r = 0; r < K; r++) {
+            if (r >= kk) break;
+            w[r] = QP_FMA(U.cwg[h + c][r][0], l[c], w[r]);
+            l[c] = QP_FMA(U.cwg[h + c][r][1], w[r], l[c]);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) L[(size_t)(J + h + c) * ld + i] = l[c];
+      }
+#pragma unroll
+      for (int r = 0; r < K; r++) if (r < kk) Wst[(size_t)r * n + i] = w[r];
+    }
 }
 
 #endif

@@ -67,6 +67,7 @@ typedef emu_double4 qp_double4;
 #define QP_OPAQUE(x) do { } while (0)
 #define QP_OPAQUE_V(x) do { } while (0)
 #define QP_FRESH_LANE(lane) (lane)
+#define QP_CALL_BLOCK() 1
 #define QP_ALWAYS_INLINE
 /* emulation: one "CU", wavefront w sits on "SIMD" w & 3 (exercises the panel-wave rotation) */
 #define QP_HW_CU_KEY() 0
@@ -102,6 +103,17 @@ static __device__ __forceinline__ int qp_fresh_lane_() {
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
 }
 #define QP_FRESH_LANE(lane) qp_fresh_lane_()
+/* A wave-uniform "true" the compiler cannot see through: `if (QP_CALL_BLOCK()) callee(...)` gives the call a basic block
+ * of its own behind a scalar branch.  Why: ROCm 7.2's register allocator saves caller-saved VGPRs around a call with
+ * copies at the top of the block that holds the call; when that block starts with the `s_or_b64 exec` closing a divergent
+ * loop, the copies land AHEAD of it and run with the loop's lanes still switched off (tools/scan_exec_prologue.py finds
+ * them in the -save-temps assembly; __graft_entry__.build() runs it over the shipped library). */
+static __device__ __forceinline__ int qp_opaque_true_() {
+  int one;
+  asm volatile("s_mov_b32 %0, 1" : "=s"(one));
+  return one;
+}
+#define QP_CALL_BLOCK() qp_opaque_true_()
 #define QP_ALWAYS_INLINE __attribute__((always_inline))
 /* where this wavefront runs: HW_REG_HW_ID (id 4: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and
  * HW_REG_XCC_ID (id 20, bits 3:0) -- s_getreg_b32 with (size-1) << 11 | offset << 6 | id */

@@ -325,7 +325,8 @@ QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
   if (tid == 0) { I.s.nb_sigma_changed = nchg; I.s.n_sigma_updates++; }
   __syncthreads();
   double thr = qmin(st.max_rank_update_fraction * (double)(n + m), 0.25 * (double)st.max_rank_update);
-  if (V.offload) thr = -1.0; /* coop mode: the factor is rebuilt by many workgroups instead of updated by one (speed policy, same matrix) */
+  if (V.offload && V.update_rank_threshold >= 0) thr = qmin(thr, (double)V.update_rank_threshold); /* coop mode: beyond its threshold the factor is rebuilt by many workgroups
+                                                                        instead of updated by one (speed policy, same matrix) */
   int nupd = 0;
   if (V.kkt) {
     /* FACTORIZE_KKT (iteration.c:135-144, solver_interface.c:463-481): every branch that changes anything ends in
@@ -570,7 +571,9 @@ QPN double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const
   __syncthreads();
   for (int j = tid; j < n; j += QP_T) { const double r = a.Aty()[j] + 1.0 * a.q()[j]; rhs[j] = r; sol[j] = r; }
   __syncthreads();
-  dense_solve(LQ, DgQ, n, V.ld, sol, lds, V.lds_bytes);
+  /* QP_CALL_BLOCK: see qpalm_device.h (ROCm 7.2 places live-range copies around this call ahead of the exec restore
+   * of the loop above; the lane index of one shuffle step of the reduction below then held garbage on the hardware) */
+  if (QP_CALL_BLOCK()) dense_solve(LQ, DgQ, n, V.ld, sol, lds, V.lds_bytes);
   double vm[1] = {0.0}, vs[2] = {0.0, 0.0};
   for (int j = tid; j < n; j += QP_T) vs[0] += rhs[j] * sol[j];
   for (int i = tid; i < m; i += QP_T) { const double yv = a.y()[i]; vs[1] += yv > 0 ? yv * a.bmax()[i] : yv * a.bmin()[i]; }
@@ -642,6 +645,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     const bool resume = (QP_UNIFORM(I.s.pend_stage) != 0); /* coop mode: the host has done this iteration's factorisation / solve */
     if (resume) {
       la = I.s.pend_la; action = I.s.pend_action; kind = I.s.pend_kind; nchange = I.s.pend_nchange; gam = I.s.pend_gam;
+      if (la == 4) { n_sig = nchange; nchange = 0; }
       __syncthreads();
       if (tid == 0) I.s.pend_stage = 0;
       __syncthreads();
@@ -856,14 +860,17 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     }
     } /* !dual_init */
     QP_OPAQUE(a.b);
-    if (V.offload && !resume && !V.kkt && (la == 1 || la == 3 || la == 7 || (kind == QP_KIND_NEWTON && la == 0))) {
-      /* coop mode: hand the factorisation (and the Newton solve that follows it) to the host's multi-workgroup kernels.  Rank
-       * updates (la == 2, 4) stay here; with the coop policy they do not occur (update_rank_threshold = 0, sigma changes reset) */
+    if (V.offload && !resume && !V.kkt && (la == 1 || la == 3 || la == 7 || (kind == QP_KIND_NEWTON && la == 0) || (V.offload >= 2 && (la == 2 || la == 4)))) {
+      /* coop mode: hand the factorisation or the rank update (and the Newton solve that follows it) to the host's multi-workgroup
+       * kernels.  With offload == 1 the rank updates (la == 2, 4) stay on this workgroup and only the solve after them goes to the host */
       if (kind == QP_KIND_NEWTON && la != 7) {
         for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1; /* ldlsolveLD_neg_dphi's right-hand side */
       }
       __syncthreads();
-      if (tid == 0) { I.s.pend_stage = 1; I.s.pend_la = (la == 1 || la == 3 || la == 7) ? la : 0; I.s.pend_action = action; I.s.pend_kind = kind; I.s.pend_nchange = nchange; I.s.pend_gam = gam; }
+      if (tid == 0) {
+        I.s.pend_stage = 1; I.s.pend_la = (la == 1 || la == 3 || la == 7 || la == 2 || la == 4) ? la : 0; I.s.pend_action = action; I.s.pend_kind = kind;
+        I.s.pend_nchange = (la == 4) ? n_sig : nchange; I.s.pend_gam = gam;
+      }
       __syncthreads();
       break;
     }
@@ -895,12 +902,19 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       /* a Newton step solves right after the update: its forward substitution rides on the last sweep */
       double *fs = nullptr;
       constexpr bool FUSED = (RPT > 0) && !QP_NOFUSE; /* the large-factor sweep keeps the solve separate */
-      if (FUSED && la == 2) {
+      if (FUSED && la == 2 && !V.offload) {
         for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1; /* ldlsolveLD_neg_dphi's right-hand side */
         fs = a.d();
         __syncthreads();
       }
       dev_updown<RPT>(V, b, n, L, Dg, Wst, a.enter(), n_up, a.leave(), n_dn, I.S, lds, I.s.ticks_dbg, fs);
+      if (V.offload && !resume && !V.kkt && la == 2 && kind == QP_KIND_NEWTON) { /* coop mode: the solve with the updated factor goes to the host */
+        for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
+        __syncthreads();
+        if (tid == 0) { I.s.pend_stage = 1; I.s.pend_la = 0; I.s.pend_action = action; I.s.pend_kind = kind; I.s.pend_nchange = nchange; I.s.pend_gam = gam; }
+        __syncthreads();
+        break;
+      }
     }
     const long long t1 = QP_CLOCK();
     QP_OPAQUE(a.b);
@@ -911,7 +925,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
       if (!V.kkt && !resume) {
-        const bool fused = (RPT > 0) && !QP_NOFUSE && (action == 2);
+        const bool fused = (RPT > 0) && !QP_NOFUSE && (action == 2) && !V.offload;
         if (!fused) for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
         __syncthreads();
         dense_solve(L, Dg, n, V.ld, a.d(), lds, V.lds_bytes, I.s.ticks_dbg, fused ? 2 : 0); /* 2: d already holds L^{-1} (-dphi) */
@@ -925,7 +939,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
         if (action == 3) { I.s.n_factor_Q++; I.s.ticks_factor += t1 - t0; }
         if (action == 2) { if (!V.kkt) I.s.n_rank1 += nchange; I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
         I.s.n_solve++; I.s.ticks_solve += t2 - t1;
-        if (!V.kkt && (RPT > 0) && !QP_NOFUSE && action == 2) I.s.n_fused_solve++;
+        if (!V.kkt && (RPT > 0) && !QP_NOFUSE && action == 2 && !V.offload) I.s.n_fused_solve++;
         I.s.last_fact = action;
       }
       QP_OPAQUE(a.b);

@@ -488,13 +488,18 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_form(qpg_view V, int b
   const int la = sc.pend_la, prox = (st.proximal != 0 || sc.nc_flag != 0) ? 1 : 0;
   form_schur(V, b, a.n, co_slot_L(V, slot, la == 7), false, la == 1, (la == 1 || la == 3) && prox, sc.pend_gam, S, lds, (int)blockIdx.x, (int)gridDim.x);
 }
-/* panel update of block column J by row tiles; workgroup 0 holds the diagonal tile (pass 0) and factorises the 32 x 32 block right
- * after it, in the same launch (nobody else reads it before the next launch) */
-__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_factor_update(qpg_view V, int b, int slot, int which, int J) {
+/* the first diagonal block (J = 0) */
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_factor_diag(qpg_view V, int b, int slot, int which, int J) {
+  char *lds = QP_DYN_LDS();
+  co_factor_diag(co_slot_L(V, slot, which), co_slot_D(V, slot, which), qp_arrays(V, b).n, V.ld, lds, J);
+}
+/* trailing update with the 32 columns of block J; workgroup 0 takes the item that holds the next diagonal block first and
+ * factorises that block right after it, in the same launch (nobody else reads it before the next launch) */
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_factor_trailing(qpg_view V, int b, int slot, int which, int J) {
   char *lds = QP_DYN_LDS();
   const int n = qp_arrays(V, b).n;
-  co_factor_update(co_slot_L(V, slot, which), co_slot_D(V, slot, which), n, V.ld, lds, J, (int)blockIdx.x, (int)gridDim.x);
-  if (blockIdx.x == 0) co_factor_diag(co_slot_L(V, slot, which), co_slot_D(V, slot, which), n, V.ld, lds, J);
+  co_factor_trailing(co_slot_L(V, slot, which), co_slot_D(V, slot, which), n, V.ld, lds, J, (int)blockIdx.x, (int)gridDim.x);
+  if (blockIdx.x == 0) co_factor_diag(co_slot_L(V, slot, which), co_slot_D(V, slot, which), n, V.ld, lds, J + QP_FNB);
 }
 __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_factor_rows(qpg_view V, int b, int slot, int which, int J) {
   char *lds = QP_DYN_LDS();
@@ -511,6 +516,21 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_solve(qpg_view V, int 
   else if (phase == 1) { for (int i = blockIdx.x * QP_T + threadIdx.x; i < n; i += QP_T * gridDim.x) a.d()[i] = a.temp_n()[i] / Dg[i]; }
   else if (phase == 2) co_solve_backward(L, n, V.ld, a.d(), a.temp_n(), lds, J, (int)blockIdx.x, (int)gridDim.x);
   else { for (int i = blockIdx.x * QP_T + threadIdx.x; i < n; i += QP_T * gridDim.x) a.d()[i] = a.temp_n()[i]; }
+}
+
+/* ldlupdate_entering_constraints / ldldowndate_leaving_constraints / ldlupdate_sigma_changed (solver_interface.c:407-503) of a
+ * suspended iteration, ranks r0 .. r0 + kk - 1 of the list (entering rows first, then leaving rows): phase 0 clears the running
+ * vectors (all workgroups), 1 scatters the rows (one workgroup), 2 = block column J (J >= n: write back the last stage) */
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_updown(qpg_view V, int b, int slot, int phase, int J, int r0, int kk, int n_up) {
+  __shared__ QpShared S;
+  char *lds = QP_DYN_LDS();
+  const QpArrays a = qp_arrays(V, b);
+  const int n = a.n;
+  double *L = co_slot_L(V, slot, 0), *Dg = co_slot_D(V, slot, 0), *Wst = V.Wst + (size_t)slot * V.wst_stride;
+  double *hst = Wst + (size_t)QPG_KMAX * V.nfac + QPG_DUMMY;
+  if (phase < 2) co_updown_init<QPG_KMAX>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA, n, Wst, hst, a.enter(), n_up,
+                                          a.leave(), r0, kk, phase, S, (int)blockIdx.x, (int)gridDim.x);
+  else co_updown_block<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, J, r0, kk, n_up, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 /* Diagnostic (tools/sweep_probe.py): every resident workgroup factorises Q + I/gamma of its QP and then applies `reps` times a

@@ -80,7 +80,7 @@ typedef struct {
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
   int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, place_panel_wave, narrow_rows;
-  int32_t offload, offload_pad; /* 1: dev_solve suspends at its linear-algebra site for factorisations and Newton solves (coop mode) */
+  int32_t offload, offload_pad; /* coop mode: 1 = dev_solve suspends at its linear-algebra site for factorisations and Newton solves, 2 = for rank updates too */
   int32_t kkt, nfac; /* kkt != 0: FACTORIZE_KKT, the factor slots hold the (n+m) x (n+m) KKT panel; nfac = rows of a factor slot
                         (n, or n + m in KKT mode); ld = its leading dimension */
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.

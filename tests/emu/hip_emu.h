@@ -43,7 +43,7 @@ struct Block {
   std::vector<Wave> waves;
   ucontext_t main_ctx;
   Fiber *cur;
-  int bar_count; unsigned bar_gen;
+  int bar_count; unsigned bar_gen; const char *bar_file; int bar_line;
   unsigned nthreads;
   char *dyn_lds;
 };
@@ -57,12 +57,20 @@ void yield_fiber();
 #define blockDim (emu::g_blockDim)
 #define gridDim (emu::g_gridDim)
 
-static inline void __syncthreads() {
+/* every thread of the workgroup must arrive at the SAME barrier (source line): on the hardware s_barrier only counts
+ * arrivals, so wavefronts that pair different barriers run on silently out of step -- here that aborts */
+static inline void emu_syncthreads_at(const char *file, int line) {
   emu::Block &B = emu::g_block;
   unsigned gen = B.bar_gen;
+  if (B.bar_count == 0) { B.bar_file = file; B.bar_line = line; }
+  else if (B.bar_line != line || B.bar_file != file) {
+    fprintf(stderr, "hip_emu: thread %d is at the barrier %s:%d while others wait at %s:%d\n", (int)emu::g_threadIdx.x, file, line, B.bar_file, B.bar_line);
+    abort();
+  }
   if (++B.bar_count == (int)B.nthreads) { B.bar_count = 0; B.bar_gen++; }
   else while (B.bar_gen == gen) emu::yield_fiber();
 }
+#define __syncthreads() emu_syncthreads_at(__FILE__, __LINE__)
 static inline void emu_wave_sync() {
   emu::Wave &W = emu::g_block.waves[emu::g_threadIdx.x >> 6];
   unsigned gen = W.gen;

@@ -103,6 +103,30 @@ def test_reference_status_paths(ctx, golden):
     assert int(bt.info(0).status_val) == STATUS["TIME_LIMIT_REACHED"]
 
 
+@pytest.mark.parametrize("shape", [(70, 100), (200, 400), (200, 1300), (300, 500), (1000, 2000)])
+def test_dual_objective_at_size(ctx, shape):
+    """compute_dual_objective (iteration.c:272-299) on QPs that fill several wavefronts and both kernel instances, with
+    and without scaling: status, iteration counts and the dual objective itself against the oracle.  (Round 3: the value
+    was wrong on the hardware from about 70 variables on -- a compiler fault, tools/scan_exec_prologue.py -- while every
+    small reference fixture passed.)"""
+    n, m = shape
+    if ctx.kind == "emu" and n > 200:
+        pytest.skip("the emulator covers the two small shapes")
+    p = random_qp(n, m, seed=1000, density_A=0.01 if n >= 400 else 4.0 / n, density_M=0.005 if n >= 400 else 2.0 / n)
+    for extra in (dict(scaling=0), dict(), dict(dual_objective_limit=-1e3)):
+        st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, enable_dual_termination=1, **extra)
+        bt = QpalmBatch(ctx, [p, p], ctx.default_settings(**st))
+        bt.solve()
+        o = oracle_for(p, st)
+        o.solve()
+        for k in range(2):
+            info = bt.info(k)
+            assert int(info.status_val) == o.status_val
+            assert int(info.iter) == int(o.info.iter) and int(info.iter_out) == int(o.info.iter_out)
+            assert abs(info.dual_objective - o.info.dual_objective) <= 1e-9 * max(1.0, abs(o.info.dual_objective))
+            assert abs(info.objective - o.info.objective) <= 1e-9 * max(1.0, abs(o.info.objective))
+
+
 def test_reference_dual_objective(ctx, golden):
     """test_basic_qp_dual_objective / _dual_early_termination (tests/src/test_basic_qp.c:334-362): the second resident
     factor LD_Q, compute_dual_objective on the device and the DUAL_TERMINATED exit (qpalm.c:459-468,545-583)."""
