@@ -195,11 +195,21 @@ def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
             return json.loads(r.stdout.strip().splitlines()[-1])
         probe = run(problems[:1], 1)                       # one QP alone on one core
         t_probe = probe["setup_plus_solve_s_per_qp"]
-        # ~budget_s of wall time with every core busy (a QP takes longer with all cores streaming their own factors)
-        nsample = int(max(cores, min(len(problems), cores * max(1.0, 0.5 * budget_s / max(t_probe, 1e-4)))))
-        nsample = min(nsample, len(problems))
-        passes = int(max(1, min(64, (cores * 0.5 * budget_s / max(t_probe, 1e-6)) // max(nsample, 1))))   # small QPs: the sample several times
-        res = run(problems[:nsample], cores, passes)
+        # The thread count is calibrated: at n = 1000 every thread streams its own 8 MB factor, and with all 256 hardware
+        # threads of the 2 x 64-core EPYC 9575F box busy a QP took 8.65 s instead of the 0.086 s it takes alone (30 QP/s
+        # for the whole machine).  One short run per candidate count (a quarter, half, all), the best one is used.
+        calib, best = {}, None
+        for th in sorted({max(1, cores // 4), max(1, cores // 2), cores}):
+            r = run(problems[:min(len(problems), th)], th, 1)
+            calib[th] = round(r["qps"], 3)
+            if best is None or r["qps"] > best[1]["qps"]:
+                best = (th, r)
+        threads, t_loaded = best[0], best[1]["setup_plus_solve_s_per_qp"]
+        # ~budget_s of wall time with those threads busy
+        nsample = int(min(len(problems), threads * max(1, int(budget_s / max(t_loaded, 1e-6)))))
+        passes = int(max(1, min(64, budget_s / max(nsample * t_loaded / threads, 1e-6))))   # small QPs: the sample several times
+        res = run(problems[:nsample], threads, passes)
+        cores = threads
     finally:
         for fpath in (exe, pfile):
             try:
@@ -210,9 +220,9 @@ def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
     have = bool(probe_lib["libcholmod"] and probe_lib["cholmod_h"])
     return {"value": res["qps"], "unit": "QP/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_string(),
             "setup_plus_solve_s_per_qp": res["setup_plus_solve_s_per_qp"], "solve_s_per_qp": res["solve_s_per_qp"],
-            "single_qp_alone_s": t_probe, "iter_mean": res["iter_mean"], "wall_s": res["wall_s"],
+            "single_qp_alone_s": t_probe, "iter_mean": res["iter_mean"], "wall_s": res["wall_s"], "threads_tried_qps": calib,
             "cholmod_probe": probe_lib,
-            "sample": "%d of the batch's %s QPs x %d pass(es), setup + solve timed as info.run_time does (eps 1e-6), %d pthreads pulling QPs from a "
+            "sample": "%d of the batch's %s QPs x %d pass(es), setup + solve timed as info.run_time does (eps 1e-6), %d pthreads (the fastest of the thread counts in threads_tried_qps) pulling QPs from a "
                       "shared counter (oracle/cpu_bench.c, no Python in the loop), oracle/qpalm_oracle.c (dense LDL', scalar rank-1 sweeps) "
                       "built -O3 -march=native; one QP alone on one core: %.4f s; %s"
                       % (nsample, workload, passes, cores, t_probe,

@@ -32,6 +32,24 @@
 #endif
 #define QPD __device__ __forceinline__
 #define QPN __device__ __forceinline__
+/* Which phases of the iteration are real calls (own register allocation, fewer values live across them in the loop body) instead
+ * of inlined into dev_solve: 0 none, 2 (default) the outer-iteration phases (sigma / gamma updates, store_solution, dual objective),
+ * 1 also the line search and the active sets.  Same box, round 3: spilled VGPRs of qp512::k_solve<2> 199 / 146 / 123; headline
+ * 5042-5050 / 5039-5044 / 4817-4820 QP/s (the line search as a call loses its address arithmetic: 6.0 -> 7.5 ms per QP);
+ * mpc-160 391 / 401 / 398 k QP/s. */
+#ifndef QP_PHASE_CALLS
+#define QP_PHASE_CALLS 2
+#endif
+#if QP_PHASE_CALLS && !defined(QPALM_EMU)
+#define QPP __device__ __noinline__
+#else
+#define QPP __device__ __forceinline__
+#endif
+#if QP_PHASE_CALLS == 1 && !defined(QPALM_EMU) /* 1: the per-iteration phases (line search, active sets) too; 2: only the outer-iteration phases */
+#define QPPH __device__ __noinline__
+#else
+#define QPPH __device__ __forceinline__
+#endif
 /* a real call: the callee gets its own register allocation instead of inheriting the live values of
  * the whole iteration loop.  Its pointer arguments are generic, so the callee re-types them (HBM arrays
  * are global memory, the LDS block is LDS): flat accesses would tie vmcnt to lgkmcnt. */

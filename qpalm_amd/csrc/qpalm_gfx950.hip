@@ -102,11 +102,36 @@ template <class K> static void rt_allow_lds(K kernel, size_t shmem) { /* once pe
 #define RT_STICKY() (g_rt_sticky)
 #define RT_STICKY_CLEAR() (g_rt_sticky = 0)
 #define RT_LAST_ERROR() (g_rt_err.c_str())
+/* launches go to g_rt_stream: the null stream, or the capturing stream while a launch sequence is recorded into a graph */
+static hipStream_t g_rt_stream = 0, g_rt_capture_stream = 0;
 #define RT_LAUNCH(kernel, grid, block, shmem, ...)                                         \
   do {                                                                                      \
     rt_allow_lds(kernel, (shmem));                                                          \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), 0, __VA_ARGS__);           \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), g_rt_stream, __VA_ARGS__); \
   } while (0)
+/* HIP graphs for the fixed launch chains of coop mode (one kernel node per launch, linear dependencies): the host enqueues one
+ * graph instead of up to ~500 kernels per factorisation / solve / update sweep */
+#define RT_GRAPHS 1
+typedef hipGraphExec_t rt_graph_t;
+static int rt_graph_begin() {
+  if (!g_rt_capture_stream && hipStreamCreateWithFlags(&g_rt_capture_stream, hipStreamNonBlocking) != hipSuccess) { g_rt_capture_stream = 0; return 1; }
+  if (hipStreamBeginCapture(g_rt_capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  g_rt_stream = g_rt_capture_stream;
+  return 0;
+}
+static int rt_graph_end(rt_graph_t *exec) {
+  hipGraph_t graph = nullptr;
+  g_rt_stream = 0;
+  if (hipStreamEndCapture(g_rt_capture_stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return 1; }
+  const hipError_t e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+  return 0;
+}
+#define RT_GRAPH_BEGIN() rt_graph_begin()
+#define RT_GRAPH_END(pexec) rt_graph_end(pexec)
+#define RT_GRAPH_LAUNCH(exec) rt_check(hipGraphLaunch((exec), 0), "hipGraphLaunch")
+#define RT_GRAPH_FREE(exec) (void)hipGraphExecDestroy(exec)
 #define RT_TIMED_LAUNCH(ms, kernel, grid, block, shmem, ...)                                \
   do {                                                                                      \
     hipEvent_t e0_, e1_;                                                                    \

@@ -287,7 +287,7 @@ QPN void dev_ldlupdate_sigma_scale(const QpArrays &a, int nchg) {
 /* Part 1: new sigma, rescaled At_sqrt_sigma, list of changed rows (in a.enter()).  Returns the number
  * of rank-1 updates ldlupdate_sigma_changed has to apply (0: nothing to do or a refactorisation was
  * requested); the update itself runs at dev_solve's single linear-algebra site, then part 2. */
-QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I) {
+QPP int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I) {
   const qpg_settings &st = *V.settings;
   const int n = a.n, m = a.m, tid = threadIdx.x;
   double vm[1] = {0.0}, vs[1] = {0.0};
@@ -347,7 +347,7 @@ QPN int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
   return nupd;
 }
 /* Part 2, after the rank updates: At_sqrt_sigma back to sqrt(sigma) scaling (solver_interface.c:498-502) */
-QPN void dev_update_sigma_post(const QpArrays &a, IterShared &I, int nchg) {
+QPP void dev_update_sigma_post(const QpArrays &a, IterShared &I, int nchg) {
   const int m = a.m, tid = threadIdx.x;
   for (int k = tid; k < m; k += QP_T) {
     const double s = 1.0 / a.At_scale()[k];
@@ -359,7 +359,7 @@ QPN void dev_update_sigma_post(const QpArrays &a, IterShared &I, int nchg) {
 }
 
 /* update_gamma (iteration.c:147-156) */
-QPN void dev_update_gamma(const qpg_view &V, const QpArrays &a, IterShared &I) {
+QPP void dev_update_gamma(const qpg_view &V, const QpArrays &a, IterShared &I) {
   const qpg_settings &st = *V.settings;
   __syncthreads();
   if (I.s.gamma < qp_gamma_max(st, I.s)) {
@@ -374,7 +374,7 @@ QPN void dev_update_gamma(const qpg_view &V, const QpArrays &a, IterShared &I) {
 }
 
 /* set_active_constraints + set_entering_leaving_constraints (newton.c:122-149) */
-QPN void dev_active_sets(const QpArrays &a, IterShared &I) {
+QPPH void dev_active_sets(const QpArrays &a, IterShared &I) {
   const int m = a.m;
   int cnt = 0;
   for (int i = threadIdx.x; i < m; i += QP_T) {
@@ -392,7 +392,7 @@ QPN void dev_active_sets(const QpArrays &a, IterShared &I) {
 
 /* boost_gamma (iteration.c:158-211); `ub` = Gershgorin bound of A' Sigma_active A, formed at dev_solve's
  * single linear-algebra site when there are active constraints */
-QPN void dev_boost_gamma_apply(const qpg_view &V, const QpArrays &a, IterShared &I, double ub) {
+QPP void dev_boost_gamma_apply(const qpg_view &V, const QpArrays &a, IterShared &I, double ub) {
   const qpg_settings &st = *V.settings;
   const double prev = I.s.gamma;
   double g;
@@ -415,7 +415,7 @@ QPN void dev_boost_gamma_apply(const qpg_view &V, const QpArrays &a, IterShared 
 }
 
 /* store_solution (termination.c:242-252); B12: yh is rescaled in place */
-QPN void dev_store_solution(const qpg_view &V, const QpArrays &a, int b, IterShared &I) {
+QPP void dev_store_solution(const qpg_view &V, const QpArrays &a, int b, IterShared &I) {
   __syncthreads();
   if (I.s.has_scaling) {
     for (int j = threadIdx.x; j < a.n; j += QP_T) a.sol_x()[j] = a.x()[j] * a.D()[j];
@@ -434,7 +434,7 @@ QPN void dev_store_solution(const qpg_view &V, const QpArrays &a, int b, IterSha
  * =========================================================================================== */
 QPD bool ls_greater(double ka, int ia, double kb, int ib) { return (ka > kb) || (ka == kb && ia > ib); }
 
-QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, char *lds) {
+QPPH double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, char *lds) {
   const qpg_settings &st = *V.settings;
   const int n = a.n, m = a.m, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double ginv = 1 / I.s.gamma;
@@ -565,7 +565,7 @@ QPN double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, c
 /* compute_dual_objective (iteration.c:272-299): rhs = Aty + q, solve with the resident factor of Q (LD_Q),
  * dual = -1/2 rhs' Q^{-1} rhs - sum_i (y_i > 0 ? y_i bmax_i : y_i bmin_i), unscaled by 1/c, plus the constant.
  * The two sums use the workgroup's fixed reduction tree (the CPU sums sequentially / in groups of four). */
-QPN double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const double *LQ, const double *DgQ, IterShared &I, char *lds) {
+QPP double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const double *LQ, const double *DgQ, IterShared &I, char *lds) {
   const int n = a.n, m = a.m, tid = threadIdx.x;
   double *rhs = V.dual_rhs + (size_t)b * n, *sol = a.temp_n();
   __syncthreads();

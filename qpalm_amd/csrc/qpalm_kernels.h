@@ -519,13 +519,18 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_solve(qpg_view V, int 
 }
 
 /* ldlupdate_entering_constraints / ldldowndate_leaving_constraints / ldlupdate_sigma_changed (solver_interface.c:407-503) of a
- * suspended iteration, ranks r0 .. r0 + kk - 1 of the list (entering rows first, then leaving rows): phase 0 clears the running
- * vectors (all workgroups), 1 scatters the rows (one workgroup), 2 = block column J (J >= n: write back the last stage) */
-__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_updown(qpg_view V, int b, int slot, int phase, int J, int r0, int kk, int n_up) {
+ * suspended iteration, sweep r0 / 16 over ranks r0 .. r0 + 15 of the list (entering rows first, then leaving rows; the counts are
+ * read from the QP's scalars, so that the launch chain of a sweep is the same every time and can be replayed as a graph):
+ * phase 0 clears the running vectors (all workgroups), 1 scatters the rows (one workgroup), 2 = block column J (J >= n: write
+ * back the last stage) */
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_updown(qpg_view V, int b, int slot, int phase, int J, int r0) {
   __shared__ QpShared S;
   char *lds = QP_DYN_LDS();
   const QpArrays a = qp_arrays(V, b);
   const int n = a.n;
+  const int la = V.sc[b].pend_la, n_up = (la == 2) ? V.sc[b].nb_enter : V.sc[b].pend_nchange, n_dn = (la == 2) ? V.sc[b].nb_leave : 0;
+  if (r0 >= n_up + n_dn) return;
+  const int kk = (n_up + n_dn - r0 < QPG_KMAX) ? (n_up + n_dn - r0) : QPG_KMAX;
   double *L = co_slot_L(V, slot, 0), *Dg = co_slot_D(V, slot, 0), *Wst = V.Wst + (size_t)slot * V.wst_stride;
   double *hst = Wst + (size_t)QPG_KMAX * V.nfac + QPG_DUMMY;
   if (phase < 2) co_updown_init<QPG_KMAX>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA, n, Wst, hst, a.enter(), n_up,

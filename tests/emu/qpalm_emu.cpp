@@ -29,6 +29,12 @@ static int rt_malloc(void **pp, size_t bytes) { *pp = calloc(bytes ? bytes : 1, 
 #define RT_STICKY_CLEAR() do { } while (0)
 #define RT_LAST_ERROR() (g_rt_err.c_str())
 #define RT_LAUNCH(kernel, grid, block, shmem, ...) emu::launch(kernel, emu_dim3(grid), emu_dim3(block), (shmem), __VA_ARGS__)
+#define RT_GRAPHS 0 /* the emulator runs every launch at once: nothing to record */
+typedef int rt_graph_t;
+#define RT_GRAPH_BEGIN() 1
+#define RT_GRAPH_END(pexec) 1
+#define RT_GRAPH_LAUNCH(exec) 0
+#define RT_GRAPH_FREE(exec) (void)0
 #define RT_TIMED_LAUNCH(ms, kernel, grid, block, shmem, ...)                                   \
   do {                                                                                         \
     auto t0_ = std::chrono::steady_clock::now();                                               \

@@ -51,7 +51,7 @@ def test_mpc_sequence_at_config_scale(ctx, mode):
     """mode kkt: FACTORIZE_KKT, i.e. the (n+m) x (n+m) panel with row additions / deletions -- what BASELINE.json's config 3 names
     literally ("warm-start row add/delete LDL' updates"); [hip]: 1024 QPs x 4 steps there, a 32-QP oracle sample."""
     kkt = mode == "kkt"
-    nb, nsteps, nsample, per_plant = sizes(ctx, (2, 2, 2, 2), (1024, 4, 32, 64)) if kkt else sizes(ctx, (6, 3, 6, 3), (4096, 5, 64, 64))
+    nb, nsteps, nsample, per_plant = sizes(ctx, (1, 2, 1, 1), (1024, 4, 32, 64)) if kkt else sizes(ctx, (3, 2, 3, 3), (4096, 5, 64, 64))
     ST = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, **(dict(factorization_method=0) if kkt else {}))
     probs, dyn, rng = _plants(nb, per_plant)
     n, m = probs[0].n, probs[0].m
@@ -102,7 +102,7 @@ def test_mpc_sequence_at_config_scale(ctx, mode):
 def test_warm_start_last_equals_host_round_trip(ctx):
     """qpg_batch_warm_start_last (previous solution straight from HBM) == qpalm_warm_start(solution()) bit for bit, and a
     second qpg_batch_solve on finished QPs starts over (re-armed on the device, src/qpalm.c:401-420)."""
-    nb = sizes(ctx, 3, 64)
+    nb = sizes(ctx, 1, 64)
     probs, dyn, rng = _plants(nb, per_plant=max(1, nb // 4))
     st = ctx.default_settings(**ST)
     a, b = QpalmBatch(ctx, probs, st), QpalmBatch(ctx, probs, st)
@@ -130,7 +130,7 @@ def test_warm_start_last_equals_host_round_trip(ctx):
 
 def test_pinned_host_arrays(ctx):
     """qpg_host_alloc: bounds handed over from, and solutions taken into, page-locked arrays give the same results."""
-    nb = sizes(ctx, 3, 32)
+    nb = sizes(ctx, 1, 32)
     probs, dyn, rng = _plants(nb, per_plant=max(1, nb // 4))
     bt = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
     bt.solve()

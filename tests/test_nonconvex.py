@@ -63,9 +63,9 @@ def test_reference_nonconvex_qp(ctx, golden, method):
 def test_indefinite_qps_in_a_batch(ctx):
     """indefinite and convex members in one nonconvex batch: per-QP gamma = 1/|lambda| where lambda < 0, the convex member
     falls back to settings->nonconvex = FALSE (nonconvex.c:179-182); scaled and unscaled"""
-    n, m = sizes(ctx, (40, 80), (160, 320))
+    n, m = sizes(ctx, (30, 50), (160, 320))
     probs, mats = [], []
-    for k in range(sizes(ctx, 2, 4)):
+    for k in range(sizes(ctx, 1, 4)):
         p, Q = indefinite_qp(n, m, 50 + k)
         probs.append(p); mats.append(Q)
     probs.append(random_qp(n, m, seed=77, density_A=max(0.03, 4.0 / n), density_M=max(0.02, 2.0 / n)))   # convex

@@ -31,5 +31,6 @@ python bench.py --batch 512 --no-cpu > $OUT/bench_b512.json 2>> $OUT/bench_defau
 python bench.py --workload mpc-160 --steps 5 > $OUT/bench_mpc160.json 2>> $OUT/bench_default.err
 python bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt.json 2>> $OUT/bench_default.err
 python tools/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_probe.txt 2>> $OUT/bench_default.err
-python tools/coop_timing.py 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
+python tools/coop_timing.py 512 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
+python tools/coop_config5.py 5000 > $OUT/coop_config5.txt 2>&1
 ls -la $OUT
