@@ -337,6 +337,39 @@ template <int R> QPD void qp_store_rows(qp_gdouble *p, const double *v) {
   }
 }
 #endif
+/* the update sweep's panel traffic with the non-temporal hint (an entry is read once and written once per sweep, the next sweep
+ * is ~1 ms and 4 GB of other QPs' panels away): QP_NT_PANEL 1 = the sweep's stores, 2 = its loads and stores, 3 = also the panel reads
+ * of the triangular solves, 4 = also those of the factorisation's panel update.  Measured in DESIGN section 7. */
+#ifndef QP_NT_PANEL
+#define QP_NT_PANEL 3
+#endif
+#ifdef QPALM_EMU
+#define qp_load_rows_nt qp_load_rows
+#define qp_store_rows_nt qp_store_rows
+#define QP_LDNT(lvl, p) (*(p))
+#else
+#define QP_LDNT(lvl, p) ((QP_NT_PANEL >= (lvl)) ? __builtin_nontemporal_load(p) : *(p)) /* a streaming read of the panel (level = which phase, see QP_NT_PANEL) */
+template <int R> QPD void qp_load_rows_nt(const qp_gdouble *p, double *v) {
+  if (QP_NT_PANEL < 2) { qp_load_rows<R>(p, v); return; }
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < R; k += 2) { const qp_double2 t = __builtin_nontemporal_load((const qp_gdouble2 *)(p + k)); v[k] = t.x; v[k + 1] = t.y; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = __builtin_nontemporal_load(p + k);
+  }
+}
+template <int R> QPD void qp_store_rows_nt(qp_gdouble *p, const double *v) {
+  if (QP_NT_PANEL < 1) { qp_store_rows<R>(p, v); return; }
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < R; k += 2) { qp_double2 t; t.x = v[k]; t.y = v[k + 1]; __builtin_nontemporal_store(t, (qp_gdouble2 *)(p + k)); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; k++) __builtin_nontemporal_store(v[k], p + k);
+  }
+}
+#endif
 #define QP_FNB 32
 #ifndef QP_FNT
 #define QP_FNT 2 /* row tiles per wavefront and pass of the panel update: 2 keeps accumulators + two fragment stages under 128 VGPRs */
@@ -442,7 +475,8 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, char *stage_
   constexpr int S = QP_FST, NH = QP_FKC / 4;
   static_assert(NH % S == 0, "QP_FST must divide QP_FKC / 4");
   double rb[S][NTJ];
-  auto loadb = [&](const int st, const int k) QP_ALWAYS_INLINE { qp_load_rows<NTJ>(L + (size_t)(k + l4) * ld + rowb, rb[st]); };
+  auto loadb = [&](const int st, const int k) QP_ALWAYS_INLINE { /* the panel re-read of the left-looking update */
+    if (QP_NT_PANEL >= 4) qp_load_rows_nt<NTJ>(L + (size_t)(k + l4) * ld + rowb, rb[st]); else qp_load_rows<NTJ>(L + (size_t)(k + l4) * ld + rowb, rb[st]); };
   auto mma = [&](const int st, const int buf, const int h) QP_ALWAYS_INLINE {
     double pa[NCT];
 #pragma unroll
@@ -726,7 +760,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
       for (int ch = 0; ch < NB; ch += QP_SOLVE_FCH) {
         double lv[QP_SOLVE_FCH];
 #pragma unroll
-        for (int cc = 0; cc < QP_SOLVE_FCH; cc++) lv[cc] = L[(size_t)(J + ((ch + cc < jb) ? ch + cc : jb - 1)) * ld + i];
+        for (int cc = 0; cc < QP_SOLVE_FCH; cc++) lv[cc] = QP_LDNT(3, &L[(size_t)(J + ((ch + cc < jb) ? ch + cc : jb - 1)) * ld + i]);
 #pragma unroll
         for (int cc = 0; cc < QP_SOLVE_FCH; cc++) if (ch + cc < jb) acc = QP_FMA(-lv[cc], xs[J + ch + cc], acc);
       }
@@ -772,7 +806,7 @@ QP_NI_SOLVE void dense_solve(const double *L_, const double *Dg_, int n_, int ld
           const qp_gdouble *col = L + (size_t)(J + ((c < jb) ? c : jb - 1)) * ld;
           double lv[BU];
 #pragma unroll
-          for (int u = 0; u < BU; u++) { const int i = i0 + 64 * u + lane; lv[u] = col[(i < n) ? i : n - 1]; }
+          for (int u = 0; u < BU; u++) { const int i = i0 + 64 * u + lane; lv[u] = QP_LDNT(3, &col[(i < n) ? i : n - 1]); }
 #pragma unroll
           for (int u = 0; u < BU; u++) sacc[q] = QP_FMA(lv[u], xv[u], sacc[q]);
         }
@@ -1257,7 +1291,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const size_t cstride = ok ? (size_t)ld : 0;
           double q[QD][RPT];
 #pragma unroll
-          for (int cc = 0; cc < QD; cc++) qp_load_rows<RPT>(rowp + (size_t)cc * cstride, q[cc]);
+          for (int cc = 0; cc < QD; cc++) qp_load_rows_nt<RPT>(rowp + (size_t)cc * cstride, q[cc]);
           auto group = [&](const int c0) QP_ALWAYS_INLINE {
 #pragma unroll
             for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
@@ -1290,7 +1324,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 QP_SCHED_BARRIER();
               }
               if (!(QP_KO & 1024)) /* (KO 1024: the trailing rows are neither stored nor re-loaded) */
-              qp_store_rows<RPT>(rowp + (size_t)c1 * cstride, l);
+              qp_store_rows_nt<RPT>(rowp + (size_t)c1 * cstride, l);
               if (fuse) { /* column Jp + c1 is final for these rows: its term of the forward substitution */
                 const double yv = U.ys[prv][c1];
 #pragma unroll
@@ -1298,7 +1332,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               }
               QP_SCHED_BARRIER();
               if (!(QP_KO & 1024))
-              qp_load_rows<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
+              qp_load_rows_nt<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
               if (QP_OSLEEP > 0) QP_SLEEP(QP_OSLEEP);
               QP_SCHED_BARRIER();
             }
