@@ -38,7 +38,7 @@ def _check_general(ctx, seed, count, n_lo, n_hi):
 
 def test_fuzz_general_campaign(ctx):
     if ctx.kind == "emu":
-        _check_general(ctx, 21, 16, 2, 40)
+        _check_general(ctx, 21, 10, 2, 40)
     else:
         for seed in (21, 22, 23, 24):
             _check_general(ctx, seed, 400, 2, 70)                 # the 256-thread instance (factors of at most 256 rows)
@@ -56,7 +56,7 @@ def _fma_oracle():
 def test_fuzz_kkt_with_large_sigma(ctx):
     import oracle.binding as ob
     force = dict(factorization_method=0, sigma_init=1e3)
-    plan = [(41, 16, 2, 40)] if ctx.kind == "emu" else [(41, 300, 2, 70), (42, 300, 2, 70)]
+    plan = [(41, 10, 2, 40)] if ctx.kind == "emu" else [(41, 300, 2, 70), (42, 300, 2, 70)]
     fma = _fma_oracle()
     total, iter_off, oracle_unstable = 0, [], 0
     try:

@@ -235,7 +235,7 @@ def test_fixed_qps_files_streamed_over_two_ranks(emu_lib, host_lib):
     """Config 4's entry point, solve_qps_files: fixed-format files sharded over two gloo ranks (size-sorted round robin,
     size buckets inside a shard), ONE gather to rank 0; every file against the oracle (status, iteration count, x, y, objective)."""
     import torch.multiprocessing as mp
-    paths = _fixed_paths()[::2]          # 25 of the 50 in the emulator (all 50 on the GPU, test_fixed_qps_files_on_gfx950)
+    paths = _fixed_paths()[::3]          # 17 of the 50 in the emulator (all 50 on the GPU, test_fixed_qps_files_on_gfx950)
     st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
@@ -248,7 +248,7 @@ def test_fixed_qps_files_streamed_over_two_ranks(emu_lib, host_lib):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert sorted(res) == sorted(paths)
-    assert _check_against_oracle(paths, res, host_lib, st) >= 15
+    assert _check_against_oracle(paths, res, host_lib, st) >= 10
 
 
 @pytest.mark.gpu
