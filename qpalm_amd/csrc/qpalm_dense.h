@@ -1141,6 +1141,32 @@ template <int N> QPD double qp_row_shr(double v) {
 }
 #endif
 
+/* lane R of every row of 16 lanes to all lanes of that row (DPP row_newbcast:R): no LDS, no SGPR */
+#ifdef QPALM_EMU
+template <int R> QPD double qp_row_bcast(double v) { const int lane = threadIdx.x & 63; return emu_exchange(v, (lane & ~15) | R); }
+#else
+template <int R> QPD double qp_row_bcast(double v) { /* ONE v_mov_b64_dpp: row_newbcast is the DPP control gfx90a+ allows on 64-bit moves */
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + R, 0xf, 0xf, true);
+}
+#endif
+/* ranks r = 0 .. K-1 of one column applied to a row: w_r += c0_r l, l += c1_r w_r, the pair (c0_r, c1_r) living in lane r of
+ * every 16-lane row (QP_PANEL_DPP) */
+template <int K, int R0, int R1>
+QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) {
+  if constexpr (R0 < R1 && R0 < K) {
+    const double c0 = qp_row_bcast<R0>(cw0), c1 = qp_row_bcast<R0>(cw1);
+    wrow[R0] = QP_FMA(c0, l, wrow[R0]);
+    l = QP_FMA(c1, wrow[R0], l);
+    qp_apply_ranks_dpp<K, R0 + 1, R1>(cw0, cw1, wrow, l);
+  }
+}
+/* QP_RECUR_DPP = 1: the diagonal-block recurrence of the update sweep hands the (-w, -gamma) pair of rank r to the row lanes by DPP
+ * row broadcast (the rank scalars are computed in every 16-lane row, lane & 15 = rank) instead of through the LDS table: one LDS
+ * round trip per column instead of two.  The table is still written for the wavefronts that own the rows below the block. */
+#ifndef QP_RECUR_DPP
+#define QP_RECUR_DPP 1
+#endif
+
 template <int RPT, int K>
 #ifndef QP_NI_UPDOWN
 #define QP_NI_UPDOWN QPNI
@@ -1208,9 +1234,9 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
     double acc[RPT]; /* fused forward substitution: b_i - sum over the finished columns of l_ij y_j */
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; acc[rr] = (fuse && i < n) ? fs[i] : 0.0; }
-    double alpha = 1.0, ialpha = 1.0; /* lane r of wavefront 0 carries alpha_r and 1/alpha_r */
-    const int grank = r0 + lane;
-    const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
+    double alpha = 1.0, ialpha = 1.0; /* lane r of the panel wave carries alpha_r and 1/alpha_r (QP_RECUR_DPP: lane r of each of its 16-lane rows) */
+    const int rl = QP_RECUR_DPP ? (lane & 15) : lane, grank = r0 + rl;
+    const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
     const int J0 = (jmin / NB) * NB;
     if (tid == 0) {
       const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1;
@@ -1711,7 +1737,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           }
           QP_WAVE_SYNC();
           /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
-          const double wv = (QP_KO & 32) ? wrow[0] : ((ln < kk) ? wt[ln & (K - 1)] : 0.0);
+          const int rk = QP_RECUR_DPP ? (ln & 15) : ln;
+          const double wv = (QP_KO & 32) ? wrow[0] : ((rk < kk) ? wt[rk & (K - 1)] : 0.0);
           if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
           const double d0 = qp_readlane(dreg, c1);
           const double p = sg * wv * wv * ialpha;
@@ -1732,11 +1759,16 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             const double dfin = qp_readlane(dnew, kk - 1);
             if (ln == c1) dreg = dfin;
           }
-          QP_WAVE_SYNC();
+          if (!QP_RECUR_DPP || QP_UHELP) QP_WAVE_SYNC();
           if (QP_UHELP && ln == 0) QP_FLAG_STORE(&U.prog[cur], c1 + 1); /* column c1 of table s is published */
           /* rows of the block: lane = row.  Rows <= c1 are finished, their registers may be
            * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
-          {
+          if (QP_RECUR_DPP) {
+            double l = lcur;
+            qp_apply_ranks_dpp<K, 0, 8>(-wv, -gam, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
+            if (K > 8 && kk > 8) qp_apply_ranks_dpp<K, 8, 16>(-wv, -gam, wrow, l);
+            if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;
+          } else {
             double l = lcur;
             /* the first eight entries come back from LDS together; with more than eight ranks an entry's registers are refilled with
              * the entry eight ranks further right after its two FMAs, so that the second group's LDS latency runs under the first
@@ -1985,9 +2017,16 @@ struct UpdownBigLds {
 };
 /* the recurrence on one 32 x 32 diagonal block (in U.Ld / dreg, lane = row of the block) for kk <= K ranks: leaves the table
  * (-w_j, -gamma) of the block's columns in U.cwg, the new entries in U.Ld and the new pivots in dreg; lane r carries alpha_r */
+/* QP_PANEL_DPP = 1: the rank scalars are computed in every 16-lane row of the wavefront (lane & 15 = rank) and the (-w, -gamma)
+ * pair of rank r reaches the row lanes by DPP row broadcast instead of through the LDS table (which is still written, for the
+ * rows below the block, but not waited for): one LDS round trip per column instead of two.  Measured in DESIGN section 7. */
+#ifndef QP_PANEL_DPP
+#define QP_PANEL_DPP 1
+#endif
 template <int K>
 QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const int jb, const int kk, const double sg,
                           double (&wrow)[K], double &dreg, double &alpha, double &ialpha) {
+  static_assert(K == 16 || !QP_PANEL_DPP, "the DPP form needs one rank per lane of a 16-lane row");
 #pragma unroll 1
   for (int c1 = 0; c1 < jb; c1++) {
     const int ln = QP_FRESH_LANE(lane);
@@ -1997,7 +2036,8 @@ QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const in
       for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
     }
     QP_WAVE_SYNC();
-    const double wv = (ln < kk) ? U.Wt[ln & (K - 1)] : 0.0;
+    const int rk = QP_PANEL_DPP ? (ln & (K - 1)) : ln;
+    const double wv = (rk < kk) ? U.Wt[rk & (K - 1)] : 0.0;
     const double d0 = qp_readlane(dreg, c1);
     const double p = sg * wv * wv * ialpha;
     double incl = p;
@@ -2013,8 +2053,13 @@ QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const in
     alpha = alpha * dnew * rdp;
     ialpha = ialpha * dprev * rdn;
     { const double dfin = qp_readlane(dnew, kk - 1); if (ln == c1) dreg = dfin; }
-    QP_WAVE_SYNC();
-    {
+    if (QP_PANEL_DPP) {
+      double l = lcur;
+      qp_apply_ranks_dpp<K, 0, 8>(-wv, -gam, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
+      if (K > 8 && kk > 8) qp_apply_ranks_dpp<K, 8, 16>(-wv, -gam, wrow, l);
+      if (ln > c1 && ln < jb) U.Ld[ln][c1] = l;
+    } else {
+      QP_WAVE_SYNC();
       double l = lcur;
 #pragma unroll
       for (int r = 0; r < K; r++) {
@@ -2063,8 +2108,8 @@ QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_
     } else jmin = (pre_jmin < n) ? pre_jmin : n - 1;
     jmin = QP_UNIFORM(block_imin(S, jmin));
     double alpha = 1.0, ialpha = 1.0; /* lane r of wavefront 0 carries alpha_r and 1/alpha_r */
-    const int grank = r0 + lane;
-    const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
+    const int rl = QP_PANEL_DPP ? (lane & (K - 1)) : lane, grank = r0 + rl; /* QP_PANEL_DPP: every 16-lane row of the panel wave carries the K ranks */
+    const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
     const int J0 = (jmin / NB) * NB;
     if (tid == 0) {
       tdbg[QPG_CNT_SWEEPS] += 1;
@@ -2190,9 +2235,10 @@ QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, doubl
 #pragma unroll
     for (int r = 0; r < K; r++) wrow[r] = (lane < jb && r < kk) ? Wst[(size_t)r * n + J + lane] : 0.0;
     double dreg = (lane < jb) ? U.dd[lane] : 1.0;
-    double alpha = (lane < K) ? hst[par * 2 * K + lane] : 1.0, ialpha = (lane < K) ? hst[par * 2 * K + K + lane] : 1.0;
-    const int grank = r0 + lane;
-    const double sg = (lane < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
+    const int rl = QP_PANEL_DPP ? (lane & (K - 1)) : lane;
+    double alpha = (rl < K) ? hst[par * 2 * K + rl] : 1.0, ialpha = (rl < K) ? hst[par * 2 * K + K + rl] : 1.0;
+    const int grank = r0 + rl;
+    const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
     updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha);
     if (wg == 0) {
       if (lane < K) { hst[(1 - par) * 2 * K + lane] = alpha; hst[(1 - par) * 2 * K + K + lane] = ialpha; }

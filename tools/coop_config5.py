@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qpalm_amd.problems import random_qp  # noqa: E402
 from qpalm_amd.solver import Context, QpalmBatch  # noqa: E402
 
-ctx = Context(0)
+ctx = Context(0, lib_path=os.environ.get("QPALM_LIB") or None)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 m = n
 p = random_qp(n, m, seed=55, density_A=10.0 / n, density_M=5.0 / n)
