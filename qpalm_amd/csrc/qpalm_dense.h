@@ -1151,6 +1151,19 @@ template <int R> QPD double qp_row_bcast(double v) { /* ONE v_mov_b64_dpp: row_n
 #endif
 /* ranks r = 0 .. K-1 of one column applied to a row: w_r += c0_r l, l += c1_r w_r, the pair (c0_r, c1_r) living in lane r of
  * every 16-lane row (QP_PANEL_DPP) */
+#ifdef QPALM_EMU
+template <int K, int R0, int R1>
+QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) { /* same values, one fiber round instead of 2 (R1 - R0) */
+  const int lane = threadIdx.x & 63;
+  emu_publish2(cw0, cw1);
+  for (int r = R0; r < R1 && r < K; r++) {
+    const double c0 = emu_peek((lane & ~15) | r, 0), c1 = emu_peek((lane & ~15) | r, 1);
+    wrow[r] = QP_FMA(c0, l, wrow[r]);
+    l = QP_FMA(c1, wrow[r], l);
+  }
+  emu_wave_sync();
+}
+#else
 template <int K, int R0, int R1>
 QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) {
   if constexpr (R0 < R1 && R0 < K) {
@@ -1160,6 +1173,7 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
     qp_apply_ranks_dpp<K, R0 + 1, R1>(cw0, cw1, wrow, l);
   }
 }
+#endif
 /* QP_RECUR_DPP = 1: the diagonal-block recurrence of the update sweep hands the (-w, -gamma) pair of rank r to the row lanes by DPP
  * row broadcast (the rank scalars are computed in every 16-lane row, lane & 15 = rank) instead of through the LDS table: one LDS
  * round trip per column instead of two.  The table is still written for the wavefronts that own the rows below the block. */

@@ -89,6 +89,20 @@ template <class T> static inline T emu_exchange(T v, int src) {
   T out; memcpy(&out, &r, sizeof(T));
   return out;
 }
+/* two values per lane published once, then read from any lane without further switches (the emulator's form of a run of DPP
+ * broadcasts of the same registers): emu_publish2(a, b); ... emu_peek(lane, 0 | 1) ...; emu_wave_sync(); */
+static inline void emu_publish2(double a, double b) {
+  emu::Wave &W = emu::g_block.waves[emu::g_threadIdx.x >> 6];
+  int lane = emu::g_threadIdx.x & 63;
+  memcpy(&W.slot[lane][4], &a, 8);
+  memcpy(&W.slot[lane][5], &b, 8);
+  emu_wave_sync();
+}
+static inline double emu_peek(int lane, int k) {
+  emu::Wave &W = emu::g_block.waves[emu::g_threadIdx.x >> 6];
+  double v; memcpy(&v, &W.slot[lane & 63][4 + k], 8);
+  return v;
+}
 template <class T> static inline T __shfl(T v, int src, int width = 64) {
   int lane = emu::g_threadIdx.x & 63;
   int base = lane & ~(width - 1);
