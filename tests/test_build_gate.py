@@ -1,0 +1,57 @@
+"""The build gate against the ROCm 7.2 register-allocator fault ("compiler fault"): tools/scan_exec_prologue.py
+must flag a plain VGPR-to-VGPR copy that sits between a block label and the `s_or_b64 exec, exec, ...` of that block, and must not
+flag computed values there (phis of the lanes that were active) nor copies behind the exec restore."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FAULTY = """
+_ZN5qp5127k_solveILi2EEEv8qpg_viewii:
+.LBB57_1093:
+	flat_load_dwordx2 v[12:13], v[8:9]
+	s_andn2_b64 exec, exec, s[2:3]
+	s_cbranch_execnz .LBB57_1093
+.LBB57_1094:                            ; %Flow2605
+	v_mov_b64_e32 v[76:77], v[74:75]
+	v_mov_b32_e32 v63, v113
+	s_or_b64 exec, exec, s[0:1]
+	s_barrier
+	s_swappc_b64 s[30:31], s[0:1]
+	v_mov_b32_e32 v113, v63
+"""
+
+CLEAN = """
+_ZN5qp5127k_solveILi2EEEv8qpg_viewii:
+.LBB57_1093:
+	flat_load_dwordx2 v[12:13], v[8:9]
+	s_andn2_b64 exec, exec, s[2:3]
+	s_cbranch_execnz .LBB57_1093
+.LBB57_1094:                            ; %Flow2605
+	v_add_f64 v[12:13], v[12:13], v[14:15]
+	ds_write_b64 v66, v[12:13] offset:17088
+	s_or_b64 exec, exec, s[0:1]
+	v_mov_b32_e32 v63, v113
+	s_barrier
+	s_swappc_b64 s[30:31], s[0:1]
+	v_mov_b32_e32 v113, v63
+"""
+
+
+def _scan():
+    spec = importlib.util.spec_from_file_location("scan_exec_prologue", os.path.join(ROOT, "tools", "scan_exec_prologue.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_gate_flags_copies_ahead_of_the_exec_restore(tmp_path):
+    mod = _scan()
+    bad, good = tmp_path / "bad.s", tmp_path / "good.s"
+    bad.write_text(FAULTY)
+    good.write_text(CLEAN)
+    found = mod.scan(str(bad))
+    assert [f[3] for f in mod.copies(found)] == ["v_mov_b64_e32 v[76:77], v[74:75]", "v_mov_b32_e32 v63, v113"]
+    assert all(f[0].startswith("_ZN5qp5127k_solve") and f[1] == ".LBB57_1094" for f in found)
+    found = mod.scan(str(good))
+    assert len(found) == 2 and mod.copies(found) == []   # computed values ahead of the restore are legitimate; the copy sits behind it
