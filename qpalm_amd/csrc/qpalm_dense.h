@@ -942,76 +942,96 @@ QPN void co_factor_rows(double *L_, const double *Dg_, int n, int ld, char *lds_
       if (c < jb) base[(size_t)c * ld2] = u[c] * F.dv[c];
   }
 }
-/* forward substitution, block J: every workgroup solves the 32 x 32 block itself (cheap, and the result is needed by all), then
+/* The triangular solves of coop mode work on blocks of CO_SNB = 64 columns: a launch costs its latency chain (stage the diagonal
+ * block, solve it on one wavefront, stream the rest), so fewer, wider blocks: 8.3 us per 32-column launch before, measured in
+ * DESIGN section 7.  One wavefront = 64 lanes = the rows (forward) or columns (backward) of the block. */
+#define CO_SNB 64
+struct CoSolveLds {
+  double tile[CO_SNB][CO_SNB + 1];
+  double part[CO_SNB];
+};
+/* forward substitution, block J: every workgroup solves the 64 x 64 block itself (cheap, and the result is needed by all), then
  * takes its share of the rows below: x_i -= sum_c l_ic y_c, c ascending, one fma per c (dense_solve's forward arithmetic) */
 /* (the block's own result goes to xo: every workgroup reads the block of x while workgroup 0 would overwrite it) */
 QPN void co_solve_forward(const double *L_, int n, int ld, double *x_, double *xo_, char *lds_, int J, int wg, int nwg) {
   const qp_gdouble *L = (const qp_gdouble *)L_;
   qp_gdouble *x = (qp_gdouble *)x_, *xo = (qp_gdouble *)xo_;
-  SolveLds QP_LDS_AS &T = *QP_LDS_ARG(SolveLds, lds_);
-  const int NB = QP_SNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  CoSolveLds QP_LDS_AS &T = *QP_LDS_ARG(CoSolveLds, lds_);
+  constexpr int NB = CO_SNB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int jb = (n - J < NB) ? (n - J) : NB;
   __syncthreads();
   for (int e = tid; e < NB * NB; e += QP_T) {
     const int c = e / NB, r = e % NB;
-    T.tile[0][r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+    T.tile[r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
   }
   __syncthreads();
   if (wid == 0) {
-    const int ln = lane & (NB - 1);
     double v = (lane < jb) ? x[J + lane] : 0.0;
 #pragma unroll 8
     for (int c = 0; c < NB; c++) {
       const double yc = qp_readlane(v, c);
-      v = QP_FMA(-T.tile[0][ln][c], yc, v);
+      v = QP_FMA(-T.tile[lane][c], yc, v);
     }
-    if (lane < NB) T.part[lane] = v;
+    T.part[lane] = v;
     if (wg == 0 && lane < jb) xo[J + lane] = v;
   }
   __syncthreads();
   for (int i = J + jb + wg * QP_T + tid; i < n; i += QP_T * nwg) {
     double acc = x[i];
-#pragma unroll 8
-    for (int c = 0; c < NB; c++) if (c < jb) acc = QP_FMA(-L[(size_t)(J + c) * ld + i], T.part[c], acc);
+#pragma unroll 1
+    for (int c0 = 0; c0 < NB; c0 += 16) { /* 16 column loads in flight per row */
+      double lv[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) lv[c] = QP_LDNT(3, &L[(size_t)(J + ((c0 + c < jb) ? c0 + c : jb - 1)) * ld + i]);
+#pragma unroll
+      for (int c = 0; c < 16; c++) if (c0 + c < jb) acc = QP_FMA(-lv[c], T.part[c0 + c], acc);
+    }
     x[i] = acc;
   }
 }
 /* backward substitution L' x = z in outer-product form, block J (descending): every workgroup finishes x_J itself, then takes its
- * share of the COLUMNS before the block: z_c -= sum_r l(J + r, c) x_r.  A quarter wavefront per column (32 contiguous rows of the
- * column: two per lane), fixed reduction tree: no reduction across workgroups, results independent of the grid. */
+ * share of the COLUMNS before the block: z_c -= sum_r l(J + r, c) x_r.  A quarter wavefront per column (64 contiguous rows of the
+ * column: four per lane), fixed reduction tree: no reduction across workgroups, results independent of the grid. */
 QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *xo_, char *lds_, int J, int wg, int nwg) {
   const qp_gdouble *L = (const qp_gdouble *)L_;
   qp_gdouble *x = (qp_gdouble *)x_, *xo = (qp_gdouble *)xo_;
-  SolveLds QP_LDS_AS &T = *QP_LDS_ARG(SolveLds, lds_);
-  const int NB = QP_SNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  CoSolveLds QP_LDS_AS &T = *QP_LDS_ARG(CoSolveLds, lds_);
+  constexpr int NB = CO_SNB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int jb = (n - J < NB) ? (n - J) : NB;
   __syncthreads();
   for (int e = tid; e < NB * NB; e += QP_T) {
     const int c = e / NB, r = e % NB;
-    T.tile[0][r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
+    T.tile[r][c] = (r > c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : 0.0;
   }
   __syncthreads();
   if (wid == 0) { /* lane = column of the block: x_c = z_c - sum_{r > c} l_rc x_r, r descending */
-    const int ln = lane & (NB - 1);
     double v = (lane < jb) ? x[J + lane] : 0.0;
 #pragma unroll 8
     for (int r = NB - 1; r >= 0; r--) {
       const double xr = qp_readlane(v, r);
-      v = QP_FMA(-T.tile[0][r][ln], xr, v); /* tile[r][c] = l(J + r, J + c), zero unless r > c */
+      v = QP_FMA(-T.tile[r][lane], xr, v); /* tile[r][c] = l(J + r, J + c), zero unless r > c */
     }
-    if (lane < NB) T.part[lane] = (lane < jb) ? v : 0.0;
+    T.part[lane] = (lane < jb) ? v : 0.0;
     if (wg == 0 && lane < jb) xo[J + lane] = v;
   }
   __syncthreads();
   const int grp = tid >> 4, gl = tid & 15, ngrp = QP_T / 16;
-  const double x0 = T.part[2 * gl], x1 = T.part[2 * gl + 1];
+  double xb[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) xb[k] = T.part[4 * gl + k];
   for (int c0 = (wg * ngrp); c0 < J; c0 += ngrp * nwg) {
     const int c = c0 + grp;
     double s = 0.0;
     if (c < J) {
-      const int r0 = J + 2 * gl;
-      const double l0 = (r0 < n) ? L[(size_t)c * ld + r0] : 0.0, l1 = (r0 + 1 < n) ? L[(size_t)c * ld + r0 + 1] : 0.0;
-      s = QP_FMA(l1, x1, l0 * x0);
+      const int r0 = J + 4 * gl;
+      double lv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) lv[k] = (r0 + k < n) ? QP_LDNT(3, &L[(size_t)c * ld + r0 + k]) : 0.0;
+      s = QP_FMA(lv[1], xb[1], lv[0] * xb[0]);
+      s = QP_FMA(lv[2], xb[2], s);
+      s = QP_FMA(lv[3], xb[3], s);
     }
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (c < J && gl == 0) x[c] = x[c] - s;
