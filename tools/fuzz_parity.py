@@ -17,7 +17,7 @@ for a in sys.argv[1:]:
         k, v = a.split("=", 1)
         force[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
 backend = pos[2] if len(pos) > 2 else 'hip'
-ctx = Context(0, lib_path=os.path.join(ROOT, 'tests', 'emu', 'libqpalm_gfx950_emu.so')) if backend == 'emu' else Context(0)
+ctx = Context(0, lib_path=os.path.join(ROOT, 'tests', 'emu', 'libqpalm_gfx950_emu.so')) if backend == 'emu' else Context(0, lib_path=os.environ.get('QPALM_LIB') or None)
 seed = int(pos[0]) if len(pos) > 0 else 0
 N = int(pos[1]) if len(pos) > 1 else 100
 NLO, NHI = (int(pos[3]), int(pos[4])) if len(pos) > 4 else (2, 70)   # range of n (m up to 1.7 n)
