@@ -4,7 +4,7 @@
 Golden: tests/src/test_nonconvex_qp.c:117-126 (gamma within 10 % of 1/0.0021544347, eigenvalue under-approximated), in the
 three factorization modes the reference runs (:132-139).  The dot products of LOBPCG are summed in the reference's order on
 the device, so lambda, the LOBPCG iteration count and gamma are compared with the oracle to the last bits (<= 1e-12) and
-the iterates of the solve to the usual 1e-9.  Limit: n <= 2048 (dense panel); BASELINE.json config 5 (n = 5000) does not fit."""
+the iterates of the solve to the usual 1e-9.  Factors of up to 8192 rows are supported; BASELINE.json config 5 itself (n = 5000) is tests/test_coop.py::test_config5_nonconvex_n5000."""
 import ctypes as C
 
 import numpy as np
