@@ -2061,10 +2061,12 @@ template <int K>
 QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const int jb, const int kk, const double sg,
                           double (&wrow)[K], double &dreg, double &alpha, double &ialpha) {
   static_assert(K == 16 || !QP_PANEL_DPP, "the DPP form needs one rank per lane of a 16-lane row");
+  double lnext = (lane > 0 && lane < jb) ? U.Ld[lane][0] : 0.0;
 #pragma unroll 1
   for (int c1 = 0; c1 < jb; c1++) {
     const int ln = QP_FRESH_LANE(lane);
-    const double lcur = (ln > c1 && ln < jb) ? U.Ld[ln][c1] : 0.0;
+    const double lcur = lnext;
+    lnext = (ln > c1 + 1 && ln < jb) ? U.Ld[ln][c1 + 1] : 0.0; /* in flight during this column (column NB is padding) */
     if (ln == c1) {
 #pragma unroll
       for (int r = 0; r < K; r++) U.Wt[r] = wrow[r];
@@ -2212,6 +2214,7 @@ QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_
 #define CO_UD_D 128
 #define CO_UD_L 160
 #define CO_UD_ROWS 128 /* rows of the panel per workgroup and pass */
+#define CO_UD_FIRST ((QP_T >= 256) ? 128 : 0) /* first thread of the row phase: wavefronts 2 and 3 where the workgroup has them (the emulator's has two) */
 /* phase 0 (all workgroups): Wst <- 0; phase 1 (one workgroup): the kk sparse rows of sqrt(Sigma) A scattered into it, state initialised */
 template <int K>
 QPD void co_updown_init(const int *Atp, const int *Ati, const double *Atss, const int n, double *Wst, double *hst, const int *cols, const int n_up,
@@ -2283,17 +2286,42 @@ QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, doubl
       if (lane == 0) hst[CO_UD_STAGED] = (double)J;
     }
   }
+  /* rows below the block (full blocks only: the last, ragged block has none): one row per thread of wavefronts 2 and 3 (wavefront 0
+   * is busy with the recurrence), its kk running values from / to HBM.  The first pass's 32 entries and running values are
+   * requested BEFORE the barrier, so their latency runs under the recurrence; further passes (grids smaller than the row count)
+   * load after it, 16 columns at a time. */
+  const int rt = tid - CO_UD_FIRST;
+  const bool rower = rt >= 0 && rt < CO_UD_ROWS;
+  const int i0 = J + NB + wg * CO_UD_ROWS + rt;
+  double w[K], l[NB];
+  if (rower && i0 < n) {
+#pragma unroll
+    for (int r = 0; r < K; r++) w[r] = (r < kk) ? Wst[(size_t)r * n + i0] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) l[c] = L[(size_t)(J + c) * ld + i0];
+  }
   __syncthreads();
-  /* rows below the block (full blocks only: the last, ragged block has none): one row per thread, its kk running values from / to
-   * HBM, the 32 entries of the row in two batches of 16 loads */
-  if (tid < CO_UD_ROWS)
-    for (int i = J + NB + wg * CO_UD_ROWS + tid; i < n; i += nwg * CO_UD_ROWS) {
-      double w[K];
+  if (rower && i0 < n) {
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+#pragma unroll
+      for (int r = 0; r < K; r++) {
+        if (r >= kk) break;
+        w[r] = QP_FMA(U.cwg[c][r][0], l[c], w[r]);
+        l[c] = QP_FMA(U.cwg[c][r][1], w[r], l[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NB; c++) L[(size_t)(J + c) * ld + i0] = l[c];
+#pragma unroll
+    for (int r = 0; r < K; r++) if (r < kk) Wst[(size_t)r * n + i0] = w[r];
+  }
+  if (rower)
+    for (int i = i0 + nwg * CO_UD_ROWS; i < n; i += nwg * CO_UD_ROWS) {
 #pragma unroll
       for (int r = 0; r < K; r++) w[r] = (r < kk) ? Wst[(size_t)r * n + i] : 0.0;
 #pragma unroll 1
       for (int h = 0; h < NB; h += 16) {
-        double l[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) l[c] = L[(size_t)(J + h + c) * ld + i];
 #pragma unroll
