@@ -64,6 +64,30 @@ def test_coop_matches_single_workgroup_and_oracle(ctx, extra):
         assert np.array_equal(b2.ivec("active", k), o.ivec("active"))
 
 
+def test_coop_members_of_different_sizes_and_repeated_solves(ctx):
+    """two QPs of different sizes in one coop batch, solved three times (on the GPU the launch chains of each member are recorded
+    during the second solve and replayed as graphs in the third): every solve against the oracle"""
+    (n1, m1), (n2, m2) = sizes(ctx, ((70, 100), (45, 80)), ((900, 1500), (700, 1000)))
+    probs = [random_qp(n1, m1, seed=301, density_A=max(0.01, 4.0 / n1), density_M=max(0.005, 2.0 / n1)),
+             random_qp(n2, m2, seed=302, density_A=max(0.01, 4.0 / n2), density_M=max(0.005, 2.0 / n2))]
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    ctx.set_option("coop", 1)
+    try:
+        bt = QpalmBatch(ctx, probs, ctx.default_settings(**st))
+        for rep in range(3):
+            if rep:
+                bt.warm_start(None, None)
+            bt.solve()
+            x, y = bt.solution()
+            for k, p in enumerate(probs):
+                o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
+                o.solve()
+                assert int(bt.info(k).status_val) == o.status_val == 1 and int(bt.info(k).iter) == int(o.info.iter), (rep, k)
+                assert rel(x[k][:p.n], o.x) <= RTOL and rel(y[k][:p.m], o.y) <= RTOL, (rep, k)
+    finally:
+        ctx.set_option("coop", 0)
+
+
 def test_coop_is_selected_automatically_for_one_large_qp(ctx):
     """default policy (coop = -1): at most four QPs with factors of at least 640 rows; small or many QPs keep the batch engine"""
     n, m = sizes(ctx, (40, 60), (1400, 1500))
