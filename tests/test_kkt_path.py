@@ -231,3 +231,28 @@ def test_kkt_operations_are_refused_in_schur_mode(ctx):
     from qpalm_amd.capi import QpgError
     with pytest.raises(QpgError):
         bt.op("kkt_form")
+
+
+@pytest.mark.gpu
+def test_config2_in_kkt_mode():
+    """BASELINE.json config 2's QP (n = 1000, m = 2000) with FACTORIZE_KKT: a 3000-row quasi-definite panel (the large-factor sweep,
+    k_solve<0>), row additions / deletions as the active set moves, iterative refinement -- against the oracle in KKT mode
+    (24 s of CPU) and against this engine's Schur mode."""
+    from qpalm_amd.solver import Context
+    ctx = Context(0)
+    ctx.set_option("coop", 0)
+    p = random_qp(1000, 2000, seed=1000, density_A=0.01, density_M=0.005)
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    bk = QpalmBatch(ctx, [p], ctx.default_settings(**dict(st, **KKT)))
+    bk.solve()
+    bs = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+    bs.solve()
+    o = ob.OracleQP(*p.args(), settings=ob.default_settings(**dict(st, **KKT)))
+    o.solve()
+    info = bk.info(0)
+    assert int(info.status_val) == o.status_val == 1
+    assert int(info.iter) == int(o.info.iter) and int(info.iter_out) == int(o.info.iter_out)
+    (xk, yk), (xs, ys) = bk.solution(), bs.solution()
+    assert rel(xk[0], o.x) <= 1e-8 and rel(yk[0], o.y) <= 1e-8
+    assert rel(xk[0], xs[0]) <= 1e-5 and rel(yk[0], ys[0]) <= 1e-5      # two factorisation methods, one solution (to the tolerance of the solve)
+    assert np.array_equal(bk.ivec("active", 0), o.ivec("active"))
