@@ -23,31 +23,8 @@
 #define QP_SCHED_BARRIER() do { } while (0)
 #define QP_SETPRIO(p) do { } while (0)
 #define QP_DRAIN_LDS() do { } while (0)
-#define QP_SLEEP(n) do { } while (0)
-/* LDS flags between wavefronts of one workgroup (helper wave of the update sweep) */
-#define QP_FLAG_STORE(p, v) (*(volatile int *)(p) = (v))
-#define QP_FLAG_LOAD(p) (*(volatile int *)(p))
-#define QP_FLAG_INC(p) ((*(volatile int *)(p))++)
-#define QP_SPIN_PAUSE() emu::yield_fiber()
 #else
-/* The flags and the data they guard both live in LDS, and the LDS unit executes the DS instructions
- * of a wavefront in program order, so relaxed accesses plus a compiler barrier are enough.  (Acquire /
- * release at workgroup scope would also drain vmcnt, i.e. the prefetch queue of L columns.) */
-#define QP_FLAG_STORE(p, v) do { asm volatile("" ::: "memory"); __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); } while (0)
-static __device__ __forceinline__ int qp_flag_load_(int __attribute__((address_space(3))) *p) {
-  asm volatile("" ::: "memory");
-  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  asm volatile("" ::: "memory");
-  return v;
-}
-#define QP_FLAG_LOAD(p) qp_flag_load_((p))
-#define QP_FLAG_INC(p) do { asm volatile("" ::: "memory"); (void)__hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); } while (0)
-#ifndef QP_SPIN_SLEEP
-#define QP_SPIN_SLEEP 1
-#endif
-#define QP_SPIN_PAUSE() __builtin_amdgcn_s_sleep(QP_SPIN_SLEEP)
 #define QP_SETPRIO(p) __builtin_amdgcn_s_setprio(p) /* issue priority of a wavefront on its SIMD */
-#define QP_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 #define QP_DRAIN_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory") /* diagnostic stamps: every LDS operation issued so far has returned */
 /* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
 #define QP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -71,26 +48,6 @@ QPD int qp_readlane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src)
 QPD double qp_readlane(double v, int src) { /* src is wave-uniform: v_readlane_b32 x2, result lives in SGPRs */
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
-}
-#endif
-
-/* Half-wave exchanges (v_permlane32_swap_b32: two VALU instructions per double, no LDS round trip).
- *   qp_upper_to_lower(x): lanes 0..31 receive x of lane + 32 (lanes 32..63 keep their own x)
- *   qp_lower_merge(q, l): lanes 0..31 keep q, lanes 32..63 receive l of lane - 32 */
-#ifdef QPALM_EMU
-QPD double qp_upper_to_lower(double x) { const int lane = threadIdx.x & 63; return emu_exchange(x, lane < 32 ? lane + 32 : lane); }
-QPD double qp_lower_merge(double q, double l) { const int lane = threadIdx.x & 63; const double t = emu_exchange(l, lane >= 32 ? lane - 32 : lane); return lane < 32 ? q : t; }
-#else
-typedef unsigned qp_uint2 __attribute__((ext_vector_type(2)));
-QPD double qp_upper_to_lower(double x) { /* swap(vdst = x, src0 = x): src0' = {lower: vdst.upper, upper: src0.upper} */
-  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-  const qp_uint2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double((int)b[1], (int)a[1]);
-}
-QPD double qp_lower_merge(double q, double l) { /* swap(vdst = q, src0 = l): vdst' = {lower: vdst.lower, upper: src0.lower} */
-  const qp_uint2 a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(q), (unsigned)__double2loint(l), false, false);
-  const qp_uint2 b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(q), (unsigned)__double2hiint(l), false, false);
-  return __hiloint2double((int)b[0], (int)a[0]);
 }
 #endif
 
@@ -1061,88 +1018,31 @@ QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *
  * arithmetic per entry is the same sequence of FMAs as without look-ahead.
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
-#ifndef QP_UHELP
-#define QP_UHELP 0 /* 1: wavefront 1 ("helper") applies columns [0, QP_HSPLIT) of table s to the rows of block s+1 right behind the
-                      panel wave (LDS column counter), as soon as their owners have applied table s-1 and handed them over; the
-                      panel wave applies the remaining columns at the start of the next phase.  Parity-green (emulator and
-                      MI355X, fused solve included) but NOT faster on MI355X, in any of the forms tried in round 2 (same-box
-                      A/B, 4096 QPs): default 5219 QP/s; helper with QP_HSPLIT 8 / 16 / 24: 4949 / 4946-4985 / 4993.  The panel
-                      wave gets shorter (57 -> 49-52 ms per QP) but the hand-over (the owners need ~14 us of the 22 us phase
-                      for table s-1), the helper's tail and the panel wave's reads from HBM take it back.  One finding that
-                      mattered on the way: the hardware deals the wavefronts of a workgroup to the SIMDs in the order
-                      0, 2, 1, 3, ..., so "the next wavefront" is two SIMDs further -- with the panel waves of a CU's two
-                      workgroups on SIMDs 0 and 2 each helper shared a SIMD with the other workgroup's panel wave and slowed
-                      its recurrence from 0.66 to 1.09 us per column (qp_place_panel_wave now uses SIMDs 0 and 1).
-                      Opt-in: -DQP_UHELP_512=1 (qpalm_gfx950.hip). */
-#endif
-#ifndef QP_PSPLIT
-#define QP_PSPLIT 0 /* 1: the panel wave splits the ranks of the block recurrence over its two half-waves (see dense_updown).
-                       Parity-green, but measured SLOWER on MI355X (panel wave 78 vs 61 ms per QP): a wavefront issues one
-                       fp64 VALU op per ~5 clk dependent or not, and the split's extra selects / addresses outweigh the
-                       16 FMAs it takes off each step.  Kept as an opt-in experiment (-DQP_PSPLIT=1). */
-#endif
 #ifndef QP_USQ
 #define QP_USQ 1 /* 1: the owners stage the square L(block s+1 rows, block s columns) in LDS one phase ahead and write the finished
                     diagonal blocks back, so that the panel wave (the serial chain of the sweep) never waits for HBM; costs
                     16 KB of LDS.  0: the panel wave streams that square from HBM itself (the 256-thread instance: 38 KB LDS). */
 #endif
-#ifndef QP_ASPLIT
-#define QP_ASPLIT 0 /* 1 (K = 16 with the staged square, i.e. the 512-thread instance; parity-green on the emulator and on MI355X, results
-                       bit-identical): when the panel wave applies table s-1 to the 32 rows of block s -- a third of the serial chain of a
-                       sweep, lane = row, so half of the wavefront idles -- its two half-waves split the RANKS: lanes 0..31 apply ranks
-                       0..7 of column u while lanes 32..63 apply ranks 8..15 of column u-1 to the same rows (the (column, rank) dependences
-                       form a grid; l travels from the low to the high half with v_permlane32_swap, two VALU instructions, merged with the
-                       low half's next queue entry).  33 steps of 45 instructions instead of 32 columns of 82.  Round 3 measurement
-                       (tools/sweep_probe.py, 512 workgroups, 16 ranks): this part of the panel wave 343 -> 349 us per sweep, i.e. NO gain:
-                       the step is not bound by its instruction count.  Knock-outs (QP_KO) show where the time goes: the bare FMA chain is
-                       69 us per sweep with the trailing rows idle, all LDS reads / the store / the swap add 140 us, and the trailing rows'
-                       HBM loads and stores (not their FMAs, not their LDS table reads) add another 120-140 us.  Kept as an opt-in. */
-#endif
-#ifndef QP_APF
-#define QP_APF 1 /* rank-split form only: an entry of the table is refilled with the next step's entry right after its two FMAs (no gain either) */
-#endif
-#ifndef QP_OSLEEP
-#define QP_OSLEEP 0 /* > 0 (experiment): s_sleep of that many 64-cycle units after every column of the trailing-row loop */
-#endif
-#ifndef QP_ODELAY
-#define QP_ODELAY 0 /* 1 (experiment, parity-green): the owners of the trailing rows stage the next diagonal block first and then wait (LDS flag) until
-                       the panel wave has applied table s-1 to the rows of block s, so that their HBM stream overlaps the recurrence instead.
-                       Measured (tools/sweep_probe.py): the panel wave gets 5-8 % shorter, the sweep does not (1045 vs 1063-1115 us). */
-#endif
-#ifndef QP_KO
-#define QP_KO 0 /* knock-out experiments for tools/sweep_probe.py ONLY (wrong results): bits remove single pieces of the sweep to price them:
-                   1 store of l, 2 table refills, 4 half-wave swap, 8 queue refill (rank-split loop); 16 pivot-row write, 32 its read,
-                   64 rank scalars, 128 table read-back (recurrence loop); 256 trailing rows untouched, 512 their FMAs, 1024 their HBM
-                   loads and stores */
-#endif
-#ifndef QP_PROBE_NO_OWNER_TABLE
-#define QP_PROBE_NO_OWNER_TABLE 0 /* 1 (timing experiment for tools/sweep_probe.py ONLY, wrong results): the trailing rows do not read the table from
-                                     LDS -- what the panel wave's LDS round trips cost without the other wavefronts' table reads */
-#endif
-#ifndef QP_HSPLIT
-#define QP_HSPLIT 16 /* helper variant: the helper wave applies columns [0, QP_HSPLIT) of the growing table to the rows of the next
-                        block during the phase, the panel wave the rest at the start of the next phase (multiple of 8) */
-#endif
 #ifndef QP_TQD
 #define QP_TQD 4 /* columns of L in flight per thread in the trailing-row loop (register queue) */
 #endif
-#define QP_CWG(U, buf, col) (U).cwgz[1 + (buf) * (QP_UNB + 1) + (col)]
+/* Variants of this sweep that were built, measured slower (or equal) on MI355X and removed from this file in round 4 -- helper
+ * wave (QP_UHELP / QP_HSPLIT), rank-split panel wave (QP_PSPLIT) and rank-split table application (QP_ASPLIT / QP_APF), delayed /
+ * throttled owners (QP_ODELAY / QP_OSLEEP), the knock-out timing builds (QP_KO, QP_PROBE_NO_OWNER_TABLE) -- live as a patch in
+ * tools/variants/ (tools/build_variant.sh applies it); DESIGN.md section 7 keeps their numbers. */
+#define QP_CWG(U, buf, col) (U).cwg[buf][col]
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
   double Ld[2][QP_UNB][QP_UNB + 1];
   double Lsq[QP_USQ ? 2 : 1][QP_USQ ? QP_UNB : 1][QP_UNB]; /* [parity][column][row]: the 32 x 32 square of L that the serial chain of the next phase
                                                                applies a table to (staged by the owners, see the phase loop) */
-  double Wd[2][QP_UNB][K + 1]; /* running w of the rows of block b: owners -> (helper wave ->) panel wave */
-  double cwgz[2 * QP_UNB + 3][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast: the two tables (by block parity) with an
-                                        all-zero guard column before, between and after them, so that "column -1" and "column QP_UNB" of
-                                        either table are exact no-ops (QP_CWG; the skewed half-waves of the rank-split loops read them) */
+  double Wd[2][QP_UNB][K + 1]; /* running w of the rows of block b (+ the row's substitution accumulator): owners -> panel wave */
+  double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast: the two tables, by block parity */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
   double dd[2][QP_UNB];
   double ys[2][QP_UNB];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
   double stash_acc[RPT][64];   /* ... and wavefront 0's own row accumulators while it is the panel wave */
-  int prog[2];                 /* helper variant: columns of table [parity] published so far (NB + 1: y of the block too) */
-  int hcnt[2];                 /* helper variant: rows of block [parity] handed over by their owners so far */
 };
 
 #ifdef QPALM_EMU
@@ -1169,8 +1069,8 @@ template <int R> QPD double qp_row_bcast(double v) { /* ONE v_mov_b64_dpp: row_n
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + R, 0xf, 0xf, true);
 }
 #endif
-/* ranks r = 0 .. K-1 of one column applied to a row: w_r += c0_r l, l += c1_r w_r, the pair (c0_r, c1_r) living in lane r of
- * every 16-lane row (QP_PANEL_DPP) */
+/* ranks r = R0 .. R1-1 of one column applied to a row: w_r += c0_r l, l += c1_r w_r, the pair (c0_r, c1_r) living in lane r of
+ * every 16-lane row */
 #ifdef QPALM_EMU
 template <int K, int R0, int R1>
 QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) { /* same values, one fiber round instead of 2 (R1 - R0) */
@@ -1230,8 +1130,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   typedef UpdownLds<RPT, K> UpdownLdsT;
   UpdownLdsT QP_LDS_AS &U = *QP_LDS_ARG(UpdownLdsT, lds);
   static_assert(sizeof(UpdownLds<RPT, K>) <= QPG_LDS_DEFAULT, "update scratch must fit the dynamic LDS (lds_bytes >= QPG_LDS_DEFAULT)");
-  static_assert(!(QP_USQ && QP_PSPLIT), "the staged square belongs to the default panel wave");
-  static_assert(!QP_UHELP || (QP_USQ && QP_NW >= 2), "the helper-wave variant parks columns in the staged square's LDS");
   const int NB = QP_UNB;
   /* wavefront numbering rotated so that "wavefront 0" below (panel wave, owner of the first rows) is the wavefront
    * qp_place_panel_wave picked for this workgroup; rows are owned by the ROTATED thread id throughout the sweep */
@@ -1291,18 +1189,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           U.Wd[0][i - J0][K] = acc[rr];
         }
       }
-      if (tid < 2) { U.prog[tid] = 0; U.hcnt[tid] = 0; }
-      if (tid < 3 * 2 * K) (&U.cwgz[(tid / (2 * K)) * (QP_UNB + 1)][0][0])[tid % (2 * K)] = 0.0; /* the three guard columns */
       for (int e = tid; e < jb0 * jb0; e += QP_T) {
         const int c1 = e / jb0, c = e % jb0;
         if (c > c1) U.Ld[0][c][c1] = L[(size_t)(J0 + c1) * ld + (J0 + c)];
       }
       if (tid < jb0) U.dd[0][tid] = Dg[J0 + tid];
-      if (QP_UHELP && jb0 == NB) /* phase 0: the helper wave applies table 0 to the rows of block 1 */
-        for (int e = tid; e < NB * NB; e += QP_T) {
-          const int c1 = e / NB, c = e % NB;
-          U.Lsq[0][c1][c] = (J0 + NB + c < n) ? L[(size_t)(J0 + c1) * ld + (J0 + NB + c)] : 0.0;
-        }
       if (wid == 0) {
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
@@ -1319,24 +1210,15 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       const int jb = (n - J < NB) ? (n - J) : NB;
       const int jbn = (n - Jn < NB) ? ((n - Jn > 0) ? (n - Jn) : 0) : NB; /* 0 when block s is the last one */
       const int cur = s & 1, prv = cur ^ 1;
-      const long long tph0 = QP_CLOCK();
-      long long tpe = tph0;
-      /* owners work on rows from Jo on and hand block Jo over: the block after this one, or (helper
-       * variant) the one after that */
-      const int Jo = Jn;
-      const int jbo = (n - Jo < NB) ? ((n - Jo > 0) ? (n - Jo) : 0) : NB;
-      const int wslot = cur, hslot = prv;
-      const bool own_live0 = (64 * RPT - 1 >= Jo); /* wavefront 0 still owns rows the owners work on */
-      /* helper variant: while the rows of block s+1 are wavefront 0's own, it is an owner FIRST (the helper wave waits for
-       * that hand-over) and the panel wave after; everywhere else the other way round */
-      const bool owner_first0 = QP_UHELP && own_live0 && (Jn < 64 * RPT);
+      long long tpe = QP_CLOCK();
+      const bool own_live0 = (64 * RPT - 1 >= Jn); /* wavefront 0 still owns rows the owners work on */
       auto owner_block = [&]() QP_ALWAYS_INLINE {
-        /* ===== owners: table s-1 on the rows below block s ======================================= */
+        /* ===== owners: table s-1 on the rows below block s, then the rows of block s+1 to the hand-over buffer ========= */
         const long long tt0 = QP_CLOCK();
         bool any = false;
 #pragma unroll
-        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jo && i < n); }
-        if (s > 0 && any && !(QP_KO & 256)) { /* (KO 256: the trailing rows are not touched at all) */
+        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jn && i < n); }
+        if (s > 0 && any) {
           /* One column per iteration.  Branch-free body: rows that are not below the block read/write
            * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
            * queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four ranks at a time.
@@ -1346,7 +1228,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * one address and one liveness per thread.  Rows n..ld-1 are padding of the panel (ld is a
            * multiple of 8): they are carried along (w = 0 there, nobody reads them). */
           const int i0 = tid * RPT;
-          const bool ok = (i0 >= Jo && i0 < ld);
+          const bool ok = (i0 >= Jn && i0 < ld);
           qp_gdouble *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
           const size_t cstride = ok ? (size_t)ld : 0;
           double q[QD][RPT];
@@ -1367,7 +1249,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 double cf[4][2];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                  if (QP_PROBE_NO_OWNER_TABLE) { cf[r][0] = 0.0; cf[r][1] = 0.0; QP_OPAQUE_V(cf[r][0]); QP_OPAQUE_V(cf[r][1]); continue; }
                   cf[r][0] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][1] : 0.0;
                 }
 #pragma unroll
@@ -1375,7 +1256,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                   if (rb + r < K) {
 #pragma unroll
                     for (int rr = 0; rr < RPT; rr++) {
-                      if (QP_KO & 512) continue; /* (KO 512: no FMAs on the trailing rows) */
                       w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
                       l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
                     }
@@ -1383,7 +1263,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 }
                 QP_SCHED_BARRIER();
               }
-              if (!(QP_KO & 1024)) /* (KO 1024: the trailing rows are neither stored nor re-loaded) */
               qp_store_rows_nt<RPT>(rowp + (size_t)c1 * cstride, l);
               if (fuse) { /* column Jp + c1 is final for these rows: its term of the forward substitution */
                 const double yv = U.ys[prv][c1];
@@ -1391,9 +1270,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
               }
               QP_SCHED_BARRIER();
-              if (!(QP_KO & 1024))
               qp_load_rows_nt<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
-              if (QP_OSLEEP > 0) QP_SLEEP(QP_OSLEEP);
               QP_SCHED_BARRIER();
             }
           };
@@ -1405,12 +1282,10 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
           const int i = tid * RPT + rr;
-          if (i >= Jo && i < Jo + jbo) {
+          if (i >= Jn && i < Jn + jbn) {
 #pragma unroll
-            for (int r = 0; r < K; r++) U.Wd[hslot][i - Jo][r] = w[rr][r];
-            U.Wd[hslot][i - Jo][K] = acc[rr];
-            if (QP_UHELP) QP_FLAG_INC(&U.hcnt[prv]); /* after this lane's writes (LDS runs a wavefront's operations in order) */
-            if (QP_UHELP && QP_PANEL_TIMING && i == Jo) tdbg[10] += QP_CLOCK() - tph0; /* diagnostic build: when the rows are handed over */
+            for (int r = 0; r < K; r++) U.Wd[prv][i - Jn][r] = w[rr][r];
+            U.Wd[prv][i - Jn][K] = acc[rr];
           }
         }
         if (wid == 0) {
@@ -1423,236 +1298,27 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         }
         if (tid == QP_T - 64) tdbg[2] += QP_CLOCK() - tt0; /* the last wavefront's rows live longest */
       };
-      if (wid == 0 && owner_first0) owner_block();
       if (wid == 0) {
         /* ===== panel wave ===================================================================== */
         const long long tp0 = QP_CLOCK();
-        if (QP_UHELP && lane == 0) U.prog[prv] = 0; /* re-arm the column counter of the table two phases ahead (its helper wave is done) */
         QP_SETPRIO(3); /* the serial chain of the sweep goes first on its SIMD */
-#if QP_PSPLIT
-        /* ---- rank-split panel wave.  The block has 32 rows but a wavefront has 64 lanes: the low half-wave works on
-         * ranks 0 .. H-1 (H = K/2) of column t while the high half-wave works on ranks H .. K-1 of column t-1 (the
-         * (column, rank) dependences of the recurrence form a grid: stage B of a column only needs stage A of the same
-         * column and stage B of the column before).  Per step the serial chain is H ranks = 2H dependent FMAs instead of
-         * 2K, the rank scalars of both stages are computed together (two DPP rows: lanes 0..H-1 and 16..16+H-1), the
-         * pivot-row transposition writes 2 x H values; a block takes jb + 1 steps.  Every entry still gets exactly the
-         * same FMAs in the same order (ranks ascending per column). ------------------------------------------------- */
-        constexpr int H = K / 2;
-        static_assert(!QP_UHELP, "the helper-wave variant belongs to the unsplit panel wave");
-        const int hi = lane >> 5, prow = lane & 31, roff = hi * H;
-        double wr[H];
-#pragma unroll
-        for (int r = 0; r < H; r++) wr[r] = (prow < jb) ? U.Wd[wslot][prow][roff + r] : 0.0;
-        double accp = (prow < jb) ? U.Wd[wslot][prow][K] : 0.0; /* this row's substitution accumulator (fused solve) */
-        if (s > 0) {
-          /* table s-1 applied to the rows of block s, same split: step u = low half on column u (l from HBM through a
-           * register queue), high half on column u-1 (l handed over by the low half), which also stores the final l */
-          constexpr int QD = 8;
-          const bool ldl = (hi == 0 && prow < jb);
-          qp_gdouble *rowp = ldl ? (L + (size_t)Jp * ld + J + prow) : (dummy + lane);
-          const size_t cstride = ldl ? (size_t)ld : 0;
-          const bool stl = (hi == 1 && prow < jb);
-          qp_gdouble *rows = stl ? (L + (size_t)Jp * ld + J + prow) : (dummy + lane);
-          const size_t sstride = stl ? (size_t)ld : 0;
-          double q[QD];
-#pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[cc] = rowp[(size_t)cc * cstride];
-          double lmid = 0.0; /* high half: l of column u-1 after the first H ranks */
-          auto step = [&](const int u, const double lq) QP_ALWAYS_INLINE {
-            const int col = u - hi; /* this half's column; -1 (high half, first step) and NB (low half, last step) are idle */
-            const bool act = (col >= 0 && col < NB);
-            const double QP_LDS_AS *tab = act ? &QP_CWG(U, prv, col)[roff][0] : &U.cwgz[0][0][0];
-            double l = hi ? lmid : lq;
-#pragma unroll
-            for (int r = 0; r < H; r++) {
-              wr[r] = QP_FMA(tab[2 * r], l, wr[r]);
-              l = QP_FMA(tab[2 * r + 1], wr[r], l);
-            }
-            if (hi && act) {
-              rows[(size_t)col * sstride] = l;
-              if (fuse) accp = QP_FMA(-l, U.ys[prv][col], accp); /* column Jp + col is final for this row */
-            }
-            lmid = __shfl(l, prow); /* the low half's l goes to the same row of the high half */
-          };
-          auto group = [&](const int c0) QP_ALWAYS_INLINE {
-#pragma unroll
-            for (int u = 0; u < QD; u++) {
-              const int c1 = c0 + u;
-              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
-              step(c1, q[u]);
-              QP_SCHED_BARRIER();
-              q[u] = rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free */
-              QP_SCHED_BARRIER();
-            }
-          };
-          group(0);
-#pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
-          step(NB, 0.0); /* drains the high half (column NB - 1) */
-          accp = __shfl(accp, prow + 32); /* the accumulators were kept by the high half: back to lane = row */
-        }
-        double dreg = (lane < jb) ? U.dd[cur][lane] : 1.0;          /* lane c holds the pivot of column c */
-        double dout = dreg;
-        double lnext = (lane > 0 && lane < jb) ? U.Ld[cur][lane][0] : 0.0; /* low half: original l of the coming column */
-        double lmid = 0.0, dmid = 1.0;
-        /* rank of this lane when it computes rank scalars: lanes 0..H-1 -> ranks 0..H-1 (stage A), 16..16+H-1 -> H..K-1 (B) */
-        const int sl = lane & 15, srow = lane >> 4;
-        const int srank = (srow == 0) ? sl : H + sl;
-        const bool sact = (srow < 2 && sl < H);
-        const double sg2 = (sact && srank < kk) ? ((r0 + srank < n_up) ? 1.0 : -1.0) : 0.0;
-#pragma unroll 1
-        for (int t = 0; t <= jb; t++) {
-          const int ln = QP_FRESH_LANE(lane);
-          const int lrow = ln & 31, lhi = ln >> 5;
-          const double lcur = lnext;
-          lnext = (ln > t + 1 && ln < jb) ? U.Ld[cur][ln][t + 1] : 0.0; /* in flight during this step */
-          /* pivot rows to lane = rank: row t from the low half (ranks 0..H-1), row t-1 from the high half (H..K-1) */
-          if (lrow == t - lhi && lrow < jb) {
-#pragma unroll
-            for (int r = 0; r < H; r++) U.Wt[lhi * H + r] = wr[r];
-          }
-          QP_WAVE_SYNC();
-          const bool sA = ((ln >> 4) == 0), s_on = ((ln >> 4) < 2) && ((ln & 15) < H);
-          const int rk = sA ? (ln & 15) : H + (ln & 15);
-          const bool colA = (t < jb), colB = (t >= 1);
-          const double wv = (s_on && rk < kk && (sA ? colA : colB)) ? U.Wt[rk & (K - 1)] : 0.0;
-          const double d0a = colA ? qp_readlane(dreg, (t < jb) ? t : 0) : 1.0;
-          const double d0 = sA ? d0a : (colB ? dmid : 1.0);
-          const double p = sg2 * wv * wv * ialpha;
-          double incl = p;
-          if (H > 1) incl += qp_row_shr<1>(incl);
-          if (H > 2) incl += qp_row_shr<2>(incl);
-          if (H > 4) incl += qp_row_shr<4>(incl);
-          const double excl = qp_row_shr<1>(incl);
-          const double dnew = d0 + incl, dprev = d0 + excl;
-          const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
-          const double gam = -sg2 * wv * ialpha * rdn;
-          if (s_on && (sA ? colA : colB)) { const int tc = sA ? t : t - 1; QP_CWG(U, cur, tc)[rk][0] = -wv; QP_CWG(U, cur, tc)[rk][1] = -gam; }
-          alpha = alpha * dnew * rdp;
-          ialpha = ialpha * dprev * rdn;
-          const double dA = qp_readlane(dnew, H - 1);      /* column t after the first H ranks */
-          const double dB = qp_readlane(dnew, 16 + H - 1); /* column t-1 after all ranks: its final pivot */
-          if (colB && ln == t - 1) dout = dB;
-          dmid = dA;
-          QP_WAVE_SYNC();
-          {
-            const int col = t - lhi;
-            const bool act = (col >= 0 && col < jb);
-            const double QP_LDS_AS *tab = act ? &QP_CWG(U, cur, col)[lhi * H][0] : &U.cwgz[0][0][0];
-            double l = lhi ? lmid : lcur;
-#pragma unroll
-            for (int r = 0; r < H; r++) {
-              wr[r] = QP_FMA(tab[2 * r], l, wr[r]);
-              l = QP_FMA(tab[2 * r + 1], wr[r], l);
-            }
-            if (lhi && act && lrow > col && lrow < jb) U.Ld[cur][lrow][col] = l; /* final entry of the diagonal block */
-            lmid = __shfl(l, lrow);
-          }
-          QP_SCHED_BARRIER();
-        }
-        dreg = dout;
-        QP_WAVE_SYNC(); /* the final block entries were written by the high half-wave, the code below reads them lane = row */
-#else
         double wrow[K];
         double accp;
-        constexpr bool ASPLIT = QP_ASPLIT && QP_USQ && !QP_UHELP && (K == 16);
-        if (ASPLIT && s > 0 && kk > K / 2) {
-          /* ---- rank-split form of "table s-1 applied to the rows of block s" (QP_ASPLIT).  Step u = 0 .. NB: the low half-wave
-           * (lanes 0..31, row = lane) applies ranks 0 .. H-1 of column u, the high half-wave (row = lane - 32) ranks H .. K-1 of
-           * column u-1, whose l it received from the low half at the end of the previous step.  The idle ends (high half at u = 0,
-           * low half at u = NB) read a zero guard column of the table: exact no-ops.  The high half holds the final l: it stores
-           * it and adds its term of the fused forward substitution. ------------------------------------------------------------ */
-          constexpr int H = K / 2, QD = 4;
-          const int hi = lane >> 5, prow = lane & (NB - 1), roff = hi * H;
-          double wr[H];
 #pragma unroll
-          for (int r = 0; r < H; r++) wr[r] = (prow < jb) ? U.Wd[wslot][prow][roff + r] : 0.0;
-          double acch = (prow < jb) ? U.Wd[wslot][prow][K] : 0.0;
-          const bool stl = (hi == 1 && prow < jb);
-          qp_gdouble *rows = stl ? (L + (size_t)Jp * ld + J + prow) : (dummy + lane);
-          const size_t sstride = stl ? (size_t)ld : 0;
-          /* this lane's view of table s-1: column u - hi, ranks roff .. roff + H - 1 */
-          const qp_pair QP_LDS_AS *tb = (const qp_pair QP_LDS_AS *)QP_LDS_VBASE(&QP_CWG(U, prv, -hi)[roff][0]); /* 16-byte aligned entries */
-          const double QP_LDS_AS *ysb = QP_LDS_VBASE(&U.ys[prv][0] - hi); /* ys of column u - hi (index -1 is never used with a nonzero l) */
-          double q[QD];
-#pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[cc] = U.Lsq[cur][cc][prow];
-          double l = qp_lower_merge(q[0], 0.0); /* low half: l of column 0; high half: 0 (idle in step 0) */
-          /* QP_APF: an entry of the table is consumed by two FMAs and its registers are then refilled with the same rank's entry of
-           * the NEXT step, so that the LDS round trip of a step's entries (several hundred cycles with sixteen wavefronts reading
-           * tables on the same CU; measured: a step took ~650 cycles at 45 and at 82 instructions alike) overlaps the FMA chain of
-           * the step before.  One register set: double buffering spills under the 128-VGPR cap (measured: 2x slower). */
-          qp_pair cf[H];
-          double yv = 0.0;
-          auto loadcf = [&](const int u) QP_ALWAYS_INLINE {
-            const qp_pair QP_LDS_AS *tab = tb + (size_t)u * K;
-#pragma unroll
-            for (int r = 0; r < H; r++) cf[r] = tab[r];
-            /* with the table entries, so that the term of the fused forward substitution does not wait for an LDS round trip;
-             * added unconditionally (without a fused solve nobody reads the accumulators) */
-            yv = ysb[(u > 0) ? u : 1];
-          };
-          auto step = [&](const int u, const double qnext) QP_ALWAYS_INLINE {
-            if (!QP_APF) loadcf(u);
-            const int un = (u < NB) ? u + 1 : NB; /* step NB refills with its own (guard) column: never used */
-            const qp_pair QP_LDS_AS *tabn = tb + (size_t)un * K;
-#pragma unroll
-            for (int r = 0; r < H; r++) {
-              wr[r] = QP_FMA(cf[r].x, l, wr[r]);
-              l = QP_FMA(cf[r].y, wr[r], l);
-              if (QP_APF && !(QP_KO & 2)) { cf[r] = tabn[r]; QP_SCHED_BARRIER(); }
-            }
-            const int cst = (u > 0) ? u - 1 : 0; /* the high half's column (step 0: idle, l = 0) */
-            if (!(QP_KO & 1)) rows[(size_t)cst * sstride] = l;   /* final entry (high half); the low half's intermediate value goes to its dummy cell */
-            acch = QP_FMA(-l, yv, acch);       /* column Jp + u - 1 is final for this row (low half: discarded) */
-            if (QP_APF && !(QP_KO & 2)) yv = ysb[un];
-            if (QP_KO & 4) l = qnext + l; else
-            l = qp_lower_merge(qnext, l);      /* low half: l of the next column; high half: the low half's l of this column */
-          };
-          if (QP_APF) loadcf(0);
-          auto group = [&](const int c0) QP_ALWAYS_INLINE {
-#pragma unroll
-            for (int uu = 0; uu < QD; uu++) {
-              const int u = c0 + uu;
-              const int cpre = (u + 1 + QD < NB) ? u + 1 + QD : NB - 1;
-              /* the queue holds columns u + 1 .. u + QD when step u starts (slot = column % QD, a fixed register per slot; what the
-               * low half is handed after the last column is never used: it reads the guard column in step NB) */
-              step(u, q[(uu + 1) % QD]);
-              QP_SCHED_BARRIER();
-              if (!(QP_KO & 8))
-              q[(uu + 1) % QD] = U.Lsq[cur][cpre][prow]; /* refill the slot just consumed */
-              QP_SCHED_BARRIER();
-            }
-          };
-          /* the queue as the loop needs it: slots (u + 1) % QD .. hold columns u + 1 ..; column 0 has been consumed above */
-          q[0] = U.Lsq[cur][(QD < NB) ? QD : NB - 1][prow];
-          group(0);
-#pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
-          step(NB, 0.0); /* drains the high half (column NB - 1); the low half reads the guard column */
-          /* back to lane = row: ranks H .. K-1 and the accumulator come down from the high half */
-#pragma unroll
-          for (int r = 0; r < H; r++) { wrow[r] = wr[r]; wrow[H + r] = qp_upper_to_lower(wr[r]); }
-          accp = qp_upper_to_lower(acch);
-        } else {
-#pragma unroll
-        for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[wslot][lane][r] : 0.0;
-        accp = (lane < jb) ? U.Wd[wslot][lane][K] : 0.0; /* this row's substitution accumulator (fused solve) */
-        if (s > 0 && (!QP_UHELP || QP_HSPLIT < NB)) {
+        for (int r = 0; r < K; r++) wrow[r] = (lane < jb) ? U.Wd[cur][lane][r] : 0.0;
+        accp = (lane < jb) ? U.Wd[cur][lane][K] : 0.0; /* this row's substitution accumulator (fused solve) */
+        if (s > 0) {
           /* table s-1 applied to the rows of block s (lane = row): same loop as the trailing rows,
            * deeper queue (one row per lane: registers to spare, and this wave is the critical path).
-           * Helper variant: the helper wave has applied columns [0, QP_HSPLIT) during the last phase; the rest here, L
-           * from HBM (the staged square of this block belongs to the helper wave's phase). */
-          constexpr bool PSQ = QP_USQ && !QP_UHELP;
+           * The entries of L come from the square the owners staged in LDS (QP_USQ), else from HBM. */
+          constexpr bool PSQ = QP_USQ;
           constexpr int QD = PSQ ? 4 : 8;
-          constexpr int C0 = QP_UHELP ? QP_HSPLIT : 0;
-          static_assert(C0 % QD == 0 && (NB - C0) % QD == 0, "QP_HSPLIT: a multiple of the queue depth");
           qp_gdouble *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
           const size_t cstride = (lane < jb) ? (size_t)ld : 0;
           const int lrow = lane & (NB - 1);
           double q[QD];
 #pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[cc] = PSQ ? U.Lsq[cur][C0 + cc][lrow] : rowp[(size_t)(C0 + cc) * cstride];
+          for (int cc = 0; cc < QD; cc++) q[cc] = PSQ ? U.Lsq[cur][cc][lrow] : rowp[(size_t)cc * cstride];
           /* unrolled by the queue depth: slot u of the queue is a fixed register, so the load
            * issued QD columns ago is the only one waited for (rotating the queue through register
            * moves would make every column wait for the newest load).
@@ -1686,67 +1352,12 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               QP_SCHED_BARRIER();
             }
           };
-          /* the same with QP_APF (see the rank-split form above): an entry's registers are refilled with the next column's entry of
-           * the same rank right after its two FMAs */
-          qp_pair cf[K];
-          double yv = 0.0;
-          auto column = [&](const int c1, const double lq) QP_ALWAYS_INLINE {
-            const int cn = (c1 + 1 < NB) ? c1 + 1 : NB - 1;
-            const qp_pair QP_LDS_AS *tabn = (const qp_pair QP_LDS_AS *)&QP_CWG(U, prv, cn)[0][0];
-            double l = lq;
-#pragma unroll
-            for (int rb = 0; rb < K; rb += 8) {
-              if (rb >= kk) break;
-#pragma unroll
-              for (int r = 0; r < 8; r++) {
-                if (rb + r < K) {
-                  wrow[rb + r] = QP_FMA(cf[rb + r].x, l, wrow[rb + r]);
-                  l = QP_FMA(cf[rb + r].y, wrow[rb + r], l);
-                  cf[rb + r] = tabn[rb + r];
-                  QP_SCHED_BARRIER();
-                }
-              }
-            }
-            rowp[(size_t)c1 * cstride] = l;
-            accp = QP_FMA(-l, yv, accp); /* column Jp + c1 is final for this row (without a fused solve nobody reads the accumulators) */
-            yv = U.ys[prv][cn];
-          };
-          auto group_pf = [&](const int c0) QP_ALWAYS_INLINE {
-#pragma unroll
-            for (int u = 0; u < QD; u++) {
-              const int c1 = c0 + u;
-              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
-              column(c1, q[u]);
-              QP_SCHED_BARRIER();
-              q[u] = PSQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride];
-              QP_SCHED_BARRIER();
-            }
-          };
-          constexpr bool APFU = (QP_APF == 2) && PSQ; /* 2: also in this form (measured: the 16 entries + 16 running w + queue spill under the 128-VGPR cap) */
-          if (APFU) {
-            {
-              const qp_pair QP_LDS_AS *tab0 = (const qp_pair QP_LDS_AS *)&QP_CWG(U, prv, C0)[0][0];
-#pragma unroll
-              for (int rb = 0; rb < K; rb += 8) {
-                if (rb >= kk) break;
-#pragma unroll
-                for (int r = 0; r < 8; r++) if (rb + r < K) cf[rb + r] = tab0[rb + r];
-              }
-              yv = U.ys[prv][C0];
-            }
-            group_pf(C0);
-#pragma unroll 1
-            for (int c0 = C0 + QD; c0 < NB; c0 += QD) group_pf(c0);
-          } else {
           /* first group peeled: the loop is then entered with as many memory operations in flight as
            * on its back edge, so the s_waitcnt counts inside are the steady-state ones */
-          group(C0);
+          group(0);
 #pragma unroll 1
-          for (int c0 = C0 + QD; c0 < NB; c0 += QD) group(c0);
-          }
+          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
         }
-        }
-        if (QP_ODELAY && !QP_UHELP && s > 0) { QP_WAVE_SYNC(); if (lane == 0) QP_FLAG_STORE(&U.prog[0], s); } /* table s-1 is on the rows of block s: the owners may start */
         if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[8] += QP_CLOCK() - tp0;
         const long long tp1 = QP_CLOCK();
         double dreg = (lane < jb) ? U.dd[cur][lane] : 1.0;          /* lane c holds the pivot of column c */
@@ -1764,7 +1375,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * rank scalars / table entry through LDS back to every lane / the 2 K FMAs (each stamp drains the LDS queue first) */
           long long tc0 = 0;
           if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); tc0 = QP_CLOCK(); }
-          if (!(QP_KO & 16))
           if (ln == c1) {
 #pragma unroll
             for (int r = 0; r < K; r++) wt[r] = wrow[r];
@@ -1772,7 +1382,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           QP_WAVE_SYNC();
           /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
           const int rk = QP_RECUR_DPP ? (ln & 15) : ln;
-          const double wv = (QP_KO & 32) ? wrow[0] : ((rk < kk) ? wt[rk & (K - 1)] : 0.0);
+          const double wv = (rk < kk) ? wt[rk & (K - 1)] : 0.0;
           if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
           const double d0 = qp_readlane(dreg, c1);
           const double p = sg * wv * wv * ialpha;
@@ -1784,7 +1394,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const double excl = qp_row_shr<1>(incl);
           const double dnew = d0 + incl, dprev = d0 + excl;
           const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
-          const double gam = (QP_KO & 64) ? wv : -sg * wv * ialpha * rdn;
+          const double gam = -sg * wv * ialpha * rdn;
           if (QP_PANEL_TIMING == 2) { double gg = gam; QP_OPAQUE_V(gg); const long long t = QP_CLOCK(); if (lane == 0) tdbg[9] += t - tc0; tc0 = t; }
           if (ln < K) { QP_CWG(U, cur, c1)[ln][0] = -wv; QP_CWG(U, cur, c1)[ln][1] = -gam; } /* stored negated: plain FMAs below */
           alpha = alpha * dnew * rdp;
@@ -1793,8 +1403,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             const double dfin = qp_readlane(dnew, kk - 1);
             if (ln == c1) dreg = dfin;
           }
-          if (!QP_RECUR_DPP || QP_UHELP) QP_WAVE_SYNC();
-          if (QP_UHELP && ln == 0) QP_FLAG_STORE(&U.prog[cur], c1 + 1); /* column c1 of table s is published */
+          if (!QP_RECUR_DPP) QP_WAVE_SYNC();
           /* rows of the block: lane = row.  Rows <= c1 are finished, their registers may be
            * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
           if (QP_RECUR_DPP) {
@@ -1810,17 +1419,14 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             const qp_pair QP_LDS_AS *tab = (const qp_pair QP_LDS_AS *)&QP_CWG(U, cur, c1)[0][0];
             qp_pair cf[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-              if (QP_KO & 128) { cf[r].x = wv; cf[r].y = gam; continue; }
-              cf[r] = tab[r];
-            }
+            for (int r = 0; r < 8; r++) cf[r] = tab[r];
             if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[10] += t - tc0; tc0 = t; }
             if (K > 8 && kk > 8) {
 #pragma unroll
               for (int r = 0; r < 8; r++) {
                 wrow[r] = QP_FMA(cf[r].x, l, wrow[r]);
                 l = QP_FMA(cf[r].y, wrow[r], l);
-                if (!(QP_KO & 128)) cf[r] = tab[(8 + r < K) ? 8 + r : r];
+                cf[r] = tab[(8 + r < K) ? 8 + r : r];
                 QP_SCHED_BARRIER();
               }
 #pragma unroll
@@ -1843,7 +1449,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           QP_SCHED_BARRIER();
         }
         if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[9] += QP_CLOCK() - tp1;
-#endif
         const long long tp2 = QP_CLOCK();
         if (fuse) { /* the diagonal block is final: y_J = L_JJ^{-1} (b_J - contributions of the earlier blocks) */
           double v = accp;
@@ -1857,7 +1462,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             lc = lcn;
           }
           if (lane < jb) { U.ys[cur][lane] = v; fs[J + lane] = v; }
-          if (QP_UHELP) { QP_WAVE_SYNC(); if (lane == 0) QP_FLAG_STORE(&U.prog[cur], NB + 1); } /* y of block s is published */
         }
         /* diagonal block and pivots back to HBM (each lane re-reads what it wrote itself) */
         if (lane < jb) Dg[J + lane] = dreg;
@@ -1875,11 +1479,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live0 ? U.stash_acc[rr][lane] : 0.0;
         QP_SETPRIO(0);
         if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
-        if (QP_PANEL_TIMING == 1 && !QP_UHELP && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
+        if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
         tpe = QP_CLOCK();
       }
-      constexpr int NFREE = (QP_NW == 1) ? 0 : ((QP_UHELP && QP_NW >= 3) ? 2 : 1); /* wavefronts with a job of their own in this phase */
-      auto stage_next = [&]() QP_ALWAYS_INLINE {
+      if (wid != 0 || own_live0) owner_block();
+      constexpr int NFREE = (QP_NW == 1) ? 0 : 1; /* wavefronts with a job of their own in this phase (the panel wave) */
       if (wid >= NFREE) { /* diagonal block s+1 for the next phase */
         const int t0 = tid - 64 * NFREE, nt = QP_T - 64 * NFREE;
         if (QP_USQ) {
@@ -1891,11 +1495,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               if (s > 0) L[(size_t)(Jp + c1) * ld + (Jp + c)] = U.Ld[prv][c][c1];
               if (c < jbn) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
             }
-            if (!QP_UHELP) { /* next phase: the panel wave applies table s to the rows of block s+1 */
-              if (jbn > 0) U.Lsq[prv][c1][c] = (c < jbn) ? L[(size_t)(J + c1) * ld + (Jn + c)] : 0.0;
-            } else if (jbn == NB) { /* next phase: the helper wave applies table s+1 to the rows of block s+2 */
-              U.Lsq[prv][c1][c] = (Jn + NB + c < n) ? L[(size_t)(Jn + c1) * ld + (Jn + NB + c)] : 0.0;
-            }
+            /* next phase: the panel wave applies table s to the rows of block s+1 */
+            if (jbn > 0) U.Lsq[prv][c1][c] = (c < jbn) ? L[(size_t)(J + c1) * ld + (Jn + c)] : 0.0;
           }
         } else {
           for (int e = t0; e < jbn * jbn; e += nt) {
@@ -1904,118 +1505,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           }
         }
         if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
-      }
-      };
-      constexpr bool STAGE_FIRST = QP_ODELAY && !QP_UHELP && (QP_NW > 1);
-      /* the staging loads (next diagonal block, square under this block, pivots: all still untouched by this sweep) go first when
-       * the owners wait for the panel wave anyway; their HBM latency used to sit at the end of the owners' phase */
-      if (STAGE_FIRST) stage_next();
-      if (QP_ODELAY && !QP_UHELP && wid != 0 && s > 0) {
-        /* The trailing-row wavefronts start their FMA stream only when the panel wave has finished the part of its chain that
-         * is most sensitive to them (table s-1 on the rows of block s: dependent FMAs, which the three other wavefronts of its
-         * SIMD slow from ~70 to ~350 us per sweep when they stream at the same time; the recurrence that follows is bound by LDS
-         * round trips and loses far less).  They have slack: they need about half a phase. */
-        int seen = 0;
-        while (seen < s) { seen = QP_FLAG_LOAD(&U.prog[0]); if (seen < s) QP_SPIN_PAUSE(); }
-      }
-      if (wid != 0 || (own_live0 && !owner_first0)) owner_block();
-      if (!STAGE_FIRST) stage_next();
-
-      if (QP_UHELP && wid == 1 && jbn > 0) {
-        /* ===== helper wave: the 32 rows of block s+1 (lane = row, handed over by their owners in THIS phase as soon as
-         * these have applied table s-1) get table s, pair of columns by pair of columns right behind the panel wave (LDS
-         * column counter, no barrier): the rows are ready for the recurrence of block s+1 when the phase ends, and the
-         * panel wave -- the serial chain of the sweep, bound by its instruction count -- never applies a table itself.
-         * Fused forward substitution: the terms of the columns of block s need y of block s, which the panel wave only
-         * has at the end of the phase; the final l of those columns are parked in LDS (Lsq[0]) and the 32 terms are added,
-         * in column order like everywhere else, once the panel wave signals that ys is there. ================ */
-        const long long th0 = QP_CLOCK();
-        if (lane == 0) tdbg[14] += th0 - tph0; /* helper start delay */
-        QP_SETPRIO(2);
-        /* this wavefront's own running w leaves the registers for the duration (HBM/L2 stash; the LDS
-         * stash belongs to wavefront 0), only while its own rows are still live */
-        const bool own_live1 = (64 * RPT * 2 - 1 >= Jo);
-        qp_gdouble *hst = dummy + QPG_DUMMY;
-        if (own_live1) {
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++)
-#pragma unroll
-            for (int r = 0; r < K; r++) hst[(rr * K + r) * 64 + lane] = w[rr][r];
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) hst[(RPT * K + rr) * 64 + lane] = acc[rr];
-        }
-        const int hs = prv;
-        { /* the owners of these rows hand them over when they are through with table s-1 */
-          int got = 0;
-          while (got < jbn) { got = QP_FLAG_LOAD(&U.hcnt[prv]); if (got < jbn) QP_SPIN_PAUSE(); }
-        }
-        if (QP_PANEL_TIMING && lane == 0) tdbg[8] += QP_CLOCK() - th0; /* diagnostic build: the helper's wait for the hand-over */
-        double wrow[K];
-#pragma unroll
-        for (int r = 0; r < K; r++) wrow[r] = (lane < jbn) ? U.Wd[hs][lane][r] : 0.0;
-        double hacc = (lane < jbn) ? U.Wd[hs][lane][K] : 0.0;
-        const int lrow = lane & (NB - 1);
-        constexpr int QD = 4;
-        const size_t cstride = (lane < jbn) ? (size_t)ld : 0;
-        { /* table s, column by column as the panel wave publishes it; L from the square the owners staged in LDS last
-           * phase, final entries back to HBM and (fused solve) back into the same LDS cell for the terms added below */
-          qp_gdouble *rowp = (lane < jbn) ? (L + (size_t)J * ld + Jn + lane) : (dummy + lane);
-          double q[QD];
-#pragma unroll
-          for (int cc = 0; cc < QD; cc++) q[cc] = U.Lsq[cur][cc][lrow];
-          int avail = 0; /* columns of the table known to be published */
-          auto group = [&](const int c0) QP_ALWAYS_INLINE {
-#pragma unroll
-            for (int u = 0; u < QD; u++) {
-              const int c1 = c0 + u;
-              while (avail <= c1) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= c1) QP_SPIN_PAUSE(); }
-              double l = q[u];
-              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
-#pragma unroll
-              for (int rb = 0; rb < K; rb += 8) {
-                if (rb >= kk) break; /* ranks >= kk are exact no-ops: skipped, wave-uniform */
-                double cw[8], cg[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) { cw[r] = (rb + r < K) ? QP_CWG(U, cur, c1)[rb + r][0] : 0.0; cg[r] = (rb + r < K) ? QP_CWG(U, cur, c1)[rb + r][1] : 0.0; }
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                  if (rb + r < K) {
-                    wrow[rb + r] = QP_FMA(cw[r], l, wrow[rb + r]);
-                    l = QP_FMA(cg[r], wrow[rb + r], l);
-                  }
-                }
-              }
-              rowp[(size_t)c1 * cstride] = l;
-              QP_SCHED_BARRIER();
-              q[u] = U.Lsq[cur][cpre][lrow]; /* columns ahead still hold the staged values */
-              if (fuse && lane < NB) U.Lsq[cur][c1][lane] = l; /* y of block s comes at the end of the phase */
-              QP_SCHED_BARRIER();
-            }
-          };
-          group(0);
-#pragma unroll 1
-          for (int c0 = QD; c0 < QP_HSPLIT; c0 += QD) group(c0);
-        }
-        if (fuse) { /* the terms of the columns of block s, once the panel wave has published y of block s */
-          int avail = 0;
-          while (avail <= NB) { avail = QP_FLAG_LOAD(&U.prog[cur]); if (avail <= NB) QP_SPIN_PAUSE(); }
-#pragma unroll 8
-          for (int c = 0; c < QP_HSPLIT; c++) hacc = QP_FMA(-U.Lsq[cur][c][lrow], U.ys[cur][c], hacc);
-        }
-        if (lane < jbn) {
-#pragma unroll
-          for (int r = 0; r < K; r++) U.Wd[hs][lane][r] = wrow[r];
-          U.Wd[hs][lane][K] = hacc;
-        }
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++)
-#pragma unroll
-          for (int r = 0; r < K; r++) w[rr][r] = own_live1 ? hst[(rr * K + r) * 64 + lane] : 0.0;
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live1 ? hst[(RPT * K + rr) * 64 + lane] : 0.0;
-        QP_SETPRIO(0);
-        QP_WAVE_SYNC(); /* every lane is past its flag reads before the counter is re-armed */
-        if (lane == 0) { U.hcnt[prv] = 0; tdbg[13] += QP_CLOCK() - th0; } /* (the column counter is re-armed by the panel wave) */
       }
       __syncthreads();
       if (QP_PANEL_TIMING == 1 && tid == 0) tdbg[11] += QP_CLOCK() - tpe;

@@ -22,10 +22,6 @@
 #define QP_USQ_512 1
 #endif
 #define QP_USQ QP_USQ_512
-#ifndef QP_UHELP_512
-#define QP_UHELP_512 0
-#endif
-#define QP_UHELP QP_UHELP_512
 namespace qp512 {
 #include "qpalm_kernels.h"
 }
@@ -33,7 +29,6 @@ namespace qp512 {
 #undef QP_KSEL
 #undef QP_FKC
 #undef QP_USQ
-#undef QP_UHELP
 #undef QPALM_KERNELS_H
 #undef QPALM_DEVICE_H
 #undef QPALM_DENSE_H
@@ -43,7 +38,6 @@ namespace qp512 {
 #define QP_KSEL(RPT) 8
 #define QP_FKC 16
 #define QP_USQ 0
-#define QP_UHELP 0
 namespace qp256 {
 #include "qpalm_kernels.h"
 static_assert(sizeof(UpdownLds<1, 8>) <= 38912 && sizeof(FactorLds) + sizeof(FactorStage) + 64 <= 38912 && sizeof(SolveLds) + 8 * 256 <= 38912,
