@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--m", type=int, default=0, help="random workload: number of constraints (default 2 n)")
     ap.add_argument("--rank-threshold", type=int, default=int(os.environ.get("QPALM_RANK_THRESHOLD", "-1")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-mpc", action="store_true", help="skip the short mpc-160 lines (BASELINE.json config 3) appended to the default run's JSON")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl = RCCL) and run the gather of x, y and the info records even with ONE rank: "
                          "executes the multi-GPU path's RCCL initialisation and device-view gather on a single-GPU box (tests/test_bench_launcher.py)")
@@ -252,6 +253,79 @@ def kkt_spot_check(probs, xs, ys, idx, bmin_all=None, bmax_all=None):
     return worst
 
 
+def mpc_problems(B, rank, rng):
+    """mpc-160: one plant per 64 QPs, every QP its own initial state; the steps move the initial state (bounds of the x_0 rows)"""
+    from qpalm_amd.problems import random_mpc_qp
+    nx, nu, T = 10, 5, 10
+    plants, probs = {}, []
+    for k in range(B):
+        seed = rank * 100003 + k // 64
+        if seed not in plants:
+            plants[seed] = random_mpc_qp(T=T, nx=nx, nu=nu, seed=seed)
+        base = plants[seed]
+        x0 = 2.0 * (2 * rng.random(nx) - 1)
+        bmin, bmax = base.bmin.copy(), base.bmax.copy()
+        bmin[:nx] = x0
+        bmax[:nx] = x0
+        probs.append(type(base)(base.n, base.m, base.Qp, base.Qi, base.Qx, base.Ap, base.Ai, base.Ax, base.q, bmin, bmax))
+    return probs
+
+
+def mpc160_line(ctx, B, kkt, steps, warmup=1):
+    """BASELINE.json config 3 next to the headline: B mpc-160 QPs through a warm-started receding-horizon
+    sequence (update_bounds + warm start from the previous solution, simulations/randomMPCsequential.m:158-177), Schur panel with
+    rank updates or (kkt) the (n+m) x (n+m) KKT panel with row additions / deletions.  Returns the sub-object of the JSON line."""
+    import numpy as np
+    from qpalm_amd.solver import QpalmBatch
+    rng = np.random.default_rng(777)
+    probs = mpc_problems(B, 0, rng)
+    n, m = probs[0].n, probs[0].m
+    kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    if kkt:
+        kw["factorization_method"] = 0
+    bt = QpalmBatch(ctx, probs, ctx.default_settings(**kw))
+    bmin_all, bmax_all = ctx.pinned_array((B, m)), ctx.pinned_array((B, m))
+    bmin_all[:] = np.stack([p.bmin for p in probs])
+    bmax_all[:] = np.stack([p.bmax for p in probs])
+    sol = (ctx.pinned_array((B, n)), ctx.pinned_array((B, m)))
+    first = [True]
+
+    def step():
+        if first[0]:
+            bt.warm_start(None, None)
+            first[0] = False
+        else:
+            x0 = bmin_all[:, :10] + 0.1 * rng.standard_normal((B, 10))
+            bmin_all[:, :10] = x0
+            bmax_all[:, :10] = x0
+            if bt.update_bounds(bmin_all, bmax_all) != 0:
+                raise RuntimeError("update_bounds rejected the new bounds")
+            bt.warm_start_last()
+        bt.solve()
+        bt.solution(out=sol)
+    for _ in range(warmup):
+        step()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        kms.append(bt.last_solve_ms())
+    dt = time.perf_counter() - t0
+    infos, stats = bt.infos(), bt.stats_all()
+    st = np.array([int(i.status_val) for i in infos])
+    it = np.array([int(i.iter) for i in infos])
+    worst = kkt_spot_check(probs, sol[0], sol[1], sorted({0, B // 2, B - 1}), bmin_all, bmax_all)
+    mean = lambda f: float(np.mean([f(s) for s in stats]))
+    out = {"workload": "mpc-160 (n=%d m=%d), %d QPs, %d warm-started steps, %s" % (n, m, B, steps, "KKT panel, row add / delete" if kkt else "Schur panel, rank updates"),
+           "value": B * steps / dt, "unit": "QP/s", "ms_per_step": 1e3 * dt / steps, "kernel_ms_per_step": float(np.mean(kms)),
+           "all_solved": bool(np.all(st == 1)), "kkt_spot_check_worst_rel": worst, "iter_mean": float(it.mean()),
+           "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve")},
+           "ms_per_qp_in_kernel": {"total": mean(lambda s: s.ms_total), "factor": mean(lambda s: s.ms_factor), "update": mean(lambda s: s.ms_update),
+                                   "solve": mean(lambda s: s.ms_solve), "linesearch": mean(lambda s: s.ms_linesearch)}}
+    bt.close()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def worker(args):
     import numpy as np
@@ -303,20 +377,7 @@ def worker(args):
         wl = "random-%d: batch of %d QPs per GPU, n=%d m=%d nnz(A)~%d nnz(tril Q)~%d, eps 1e-6, scaling 10, cold start" % (
             n, B, n, m, int(probs[0].Ap[-1]), int(probs[0].Qp[-1]))
     else:
-        # one plant per 64 QPs, every QP its own initial state; the steps move the initial state (bounds of the x_0 rows)
-        nx, nu, T = 10, 5, 10
-        plants = {}
-        probs = []
-        for k in range(B):
-            seed = rank * 100003 + k // 64
-            if seed not in plants:
-                plants[seed] = random_mpc_qp(T=T, nx=nx, nu=nu, seed=seed)
-            base = plants[seed]
-            x0 = 2.0 * (2 * rng.random(nx) - 1)
-            bmin, bmax = base.bmin.copy(), base.bmax.copy()
-            bmin[:nx] = x0
-            bmax[:nx] = x0
-            probs.append(type(base)(base.n, base.m, base.Qp, base.Qi, base.Qx, base.Ap, base.Ai, base.Ax, base.q, bmin, bmax))
+        probs = mpc_problems(B, rank, rng)
         n, m = probs[0].n, probs[0].m
         wl = "mpc-160: batch of %d MPC QPs per GPU (T=10, nx=10, nu=5: n=%d m=%d nnz(A)=%d), eps 1e-6, scaling 10; every step moves " \
              "the initial states (update_bounds) and warm-starts from the previous solution" % (B, n, m, int(probs[0].Ap[-1]))
@@ -480,6 +541,12 @@ def worker(args):
                             "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve", "sweep_entries")},
                             "phase_ms_per_qp": phase_ms},
         }
+        if world == 1 and args.workload == "random-1000" and not args.no_mpc and not args.kkt and not args.n and not args.lib:
+            # config 3 in the driver's record: Schur and KKT mode, a few warm-started steps each (outside the timed region of the headline)
+            try:
+                out["mpc160"] = {"schur": mpc160_line(ctx, 8192, False, 5), "kkt": mpc160_line(ctx, 2048, True, 3)}
+            except Exception as e:   # never lose the headline line over the side figures
+                out["mpc160"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(probs, settings_kw, args.workload)
         else:

@@ -1018,6 +1018,9 @@ QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *
  * arithmetic per entry is the same sequence of FMAs as without look-ahead.
  * ------------------------------------------------------------------------------------------- */
 #define QP_UNB 32
+#ifndef QP_UNBS
+#define QP_UNBS QP_UNB /* block columns of dense_updown's sweep (dense_updown_big and the coop kernels keep QP_UNB) */
+#endif
 #ifndef QP_USQ
 #define QP_USQ 1 /* 1: the owners stage the square L(block s+1 rows, block s columns) in LDS one phase ahead and write the finished
                     diagonal blocks back, so that the panel wave (the serial chain of the sweep) never waits for HBM; costs
@@ -1033,15 +1036,15 @@ QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *
 #define QP_CWG(U, buf, col) (U).cwg[buf][col]
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
-  double Ld[2][QP_UNB][QP_UNB + 1];
-  double Lsq[QP_USQ ? 2 : 1][QP_USQ ? QP_UNB : 1][QP_UNB]; /* [parity][column][row]: the 32 x 32 square of L that the serial chain of the next phase
+  double Ld[2][QP_UNBS][QP_UNBS + 1];
+  double Lsq[QP_USQ ? 2 : 1][QP_USQ ? QP_UNBS : 1][QP_UNBS]; /* [parity][column][row]: the 32 x 32 square of L that the serial chain of the next phase
                                                                applies a table to (staged by the owners, see the phase loop) */
-  double Wd[2][QP_UNB][K + 1]; /* running w of the rows of block b (+ the row's substitution accumulator): owners -> panel wave */
-  double cwg[2][QP_UNB][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast: the two tables, by block parity */
+  double Wd[2][QP_UNBS][K + 1]; /* running w of the rows of block b (+ the row's substitution accumulator): owners -> panel wave */
+  double cwg[2][QP_UNBS][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast: the two tables, by block parity */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
-  double dd[2][QP_UNB];
-  double ys[2][QP_UNB];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
+  double dd[2][QP_UNBS];
+  double ys[2][QP_UNBS];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
   double stash_acc[RPT][64];   /* ... and wavefront 0's own row accumulators while it is the panel wave */
 };
 
@@ -1130,7 +1133,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   typedef UpdownLds<RPT, K> UpdownLdsT;
   UpdownLdsT QP_LDS_AS &U = *QP_LDS_ARG(UpdownLdsT, lds);
   static_assert(sizeof(UpdownLds<RPT, K>) <= QPG_LDS_DEFAULT, "update scratch must fit the dynamic LDS (lds_bytes >= QPG_LDS_DEFAULT)");
-  const int NB = QP_UNB;
+  const int NB = QP_UNBS;
   /* wavefront numbering rotated so that "wavefront 0" below (panel wave, owner of the first rows) is the wavefront
    * qp_place_panel_wave picked for this workgroup; rows are owned by the ROTATED thread id throughout the sweep */
   const int lane = threadIdx.x & 63, wid = QP_UNIFORM((int)((threadIdx.x >> 6) - S.panel_wave) & (QP_NW - 1)), tid = wid * 64 + lane;

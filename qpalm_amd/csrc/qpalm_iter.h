@@ -620,7 +620,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       I.s.dual_pending = st.enable_dual_termination ? 1 : 0;
       I.s.iter = 0; I.s.iter_out = 0; I.s.prev_iter = 0; I.s.no_change = 0;
       I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
-      I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot; I.s.pend_stage = 0;
+      I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot; I.s.pend_stage = 0; I.s.pend_clock = 0;
       I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
       I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0; I.s.n_fused_solve = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
@@ -647,7 +647,12 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       la = I.s.pend_la; action = I.s.pend_action; kind = I.s.pend_kind; nchange = I.s.pend_nchange; gam = I.s.pend_gam;
       if (la == 4) { n_sig = nchange; nchange = 0; }
       __syncthreads();
-      if (tid == 0) I.s.pend_stage = 0;
+      if (tid == 0) {
+        I.s.pend_stage = 0;
+        /* the host's multi-workgroup kernels ran between the suspension and this launch: their time belongs to the solve */
+        if (I.s.pend_clock != 0 && t_launch > I.s.pend_clock) I.s.solve_time += (double)(t_launch - I.s.pend_clock) * 1e-8;
+        I.s.pend_clock = 0;
+      }
       __syncthreads();
     } else
     if (dual_init) la = 7;
@@ -981,8 +986,10 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
   }
   __syncthreads();
   if (tid == 0) {
-    I.s.solve_time += (double)(QP_CLOCK() - t_launch) * 1e-8;
-    I.s.ticks_total += QP_CLOCK() - t_launch;
+    const long long t_exit = QP_CLOCK();
+    I.s.solve_time += (double)(t_exit - t_launch) * 1e-8;
+    I.s.ticks_total += t_exit - t_launch;
+    I.s.pend_clock = I.s.pend_stage ? t_exit : 0; /* suspended for the host (coop mode): the clock keeps running */
     V.sc[b] = I.s;
   }
   __syncthreads();

@@ -533,8 +533,15 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_updown(qpg_view V, int
   const int kk = (n_up + n_dn - r0 < QPG_KMAX) ? (n_up + n_dn - r0) : QPG_KMAX;
   double *L = co_slot_L(V, slot, 0), *Dg = co_slot_D(V, slot, 0), *Wst = V.Wst + (size_t)slot * V.wst_stride;
   double *hst = Wst + (size_t)QPG_KMAX * V.nfac + QPG_DUMMY;
-  if (phase < 2) co_updown_init<QPG_KMAX>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA, n, Wst, hst, a.enter(), n_up,
-                                          a.leave(), r0, kk, phase, S, (int)blockIdx.x, (int)gridDim.x);
+  if (phase < 2) {
+    co_updown_init<QPG_KMAX>(V.Atp + (size_t)b * (V.m + 1), V.Ati + (size_t)b * V.nnzA, V.Atss + (size_t)b * V.nnzA, n, Wst, hst, a.enter(), n_up,
+                             a.leave(), r0, kk, phase, S, (int)blockIdx.x, (int)gridDim.x);
+    if (phase == 1 && blockIdx.x == 0 && threadIdx.x == 0) { /* the sweep's work counters, as dense_updown keeps them (QPGStats.n_sweeps, sweep_entries) */
+      const int J0 = ((int)hst[CO_UD_JMIN] / QP_UNB) * QP_UNB;
+      V.sc[b].ticks_dbg[QPG_CNT_SWEEPS] += 1;
+      V.sc[b].ticks_dbg[QPG_CNT_SWEEP_ENTRIES] += (long long)(n - J0) * (n - J0 - 1) / 2 + (n - J0);
+    }
+  }
   else co_updown_block<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, J, r0, kk, n_up, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 

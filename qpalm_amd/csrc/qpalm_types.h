@@ -69,6 +69,8 @@ typedef struct {
    * 7 LD_Q of the dual objective; 0 no factorisation) and, for a Newton step (pend_kind == 0, pend_la != 7), to solve for d */
   int32_t pend_stage, pend_la, pend_action, pend_kind, pend_nchange, pend_pad;
   double pend_gam;
+  int64_t pend_clock; /* device clock (100 MHz, the same counter in every launch) when the iteration was suspended: the time the host's
+                         kernels take until it resumes is added to solve_time, so that run_time and time_limit see wall time (qpalm.c:680-723) */
   int32_t dual_pending, kkt_first; /* kkt_first: solver->first_factorization (types.h:176), KKT path; dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
   /* work counters (device side statistics for the roofline accounting in bench.py) */
   int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_fused_solve; /* n_fused_solve: Newton solves whose forward substitution rode on the last update sweep (L streamed once less) */

@@ -66,9 +66,11 @@ def _solve_local(problems, make_batch):
         bt = make_batch([problems[k] for k in bucket])
         bt.solve()
         info = pack_info(bt)
+        X, Y = bt.solution()   # ONE device-to-host copy per bucket (solution_of() copies the whole batch on every call)
+        dims = getattr(bt, "dims", None)
         for pos, k in enumerate(bucket):
-            x, y = bt.solution_of(pos)
-            xs[k], ys[k], infos[k] = x.copy(), y.copy(), info[pos]
+            nk, mk = dims[pos] if dims is not None else (int(problems[k].n), int(problems[k].m))
+            xs[k], ys[k], infos[k] = X[pos, :nk].copy(), Y[pos, :mk].copy(), info[pos]
         if hasattr(bt, "close"):
             bt.close()
     return xs, ys, infos

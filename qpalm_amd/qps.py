@@ -108,8 +108,9 @@ def solve_qps_files(ctx, paths, settings=None, rank=0, world=1, host_lib=None, d
         bt = QpalmBatch(ctx, [sub[k] for k in bucket], settings)
         bt.solve()
         infos = bt.infos()
+        X, Y = bt.solution()   # one copy per bucket
         for pos, k in enumerate(bucket):
-            x, y = bt.solution_of(pos)
-            out[paths[mine[k]]] = (x.copy(), y.copy(), infos[pos])
+            nk, mk = bt.dims[pos]
+            out[paths[mine[k]]] = (X[pos, :nk].copy(), Y[pos, :mk].copy(), infos[pos])
         bt.close()
     return out

@@ -56,7 +56,67 @@ def run_case(ctx, p, st, warm):
     info = bt.info(0)
     x, y = bt.solution()
     res = dict(status=(int(info.status_val), int(o.status_val)), iter=(int(info.iter), int(o.info.iter)),
-               dx=rel(x[0], o.x), dy=rel(y[0], o.y), ymax=float(np.max(np.abs(o.y))) if o.y.size else 0.0)
+               dx=rel(x[0], o.x), dy=rel(y[0], o.y), ymax=float(np.max(np.abs(o.y))) if o.y.size else 0.0,
+               obj=(float(info.objective), float(o.info.objective)))
     bt.close()
     o.cleanup()
     return res
+
+
+# ---- when the engine and the oracle disagree on (status, iterations): is the count a property of the algorithm on this case? -------------
+_VARIANTS = {}
+
+
+def oracle_variants():
+    """the ORACLE's own source compiled three ways (TEST INFRASTRUCTURE): as shipped (no contraction), with fused multiply-adds
+    (-O3 -ffp-contract=fast -mfma: what the device's explicit fma() in SpMV dots and the LDL' kernels corresponds to) and -Ofast -mfma
+    (re-associated sums as well: the device's reductions are trees).  Built once per process."""
+    import os
+    import subprocess
+    if not _VARIANTS:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for name, flags in (("fma", ["-O3", "-ffp-contract=fast", "-mfma"]), ("ofast", ["-Ofast", "-mfma"])):
+            out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "libqpalm_oracle_%s_%d.so" % (name, os.getpid()))
+            subprocess.check_call(["gcc", "-std=c99", "-fPIC", "-shared", "-o", out, os.path.join(root, "oracle", "qpalm_oracle.c"), "-lm"] + flags)
+            _VARIANTS[name] = out
+        import atexit
+        atexit.register(lambda: [os.remove(f) for f in _VARIANTS.values() if os.path.exists(f)])
+    return _VARIANTS
+
+
+def oracle_outcomes(p, st, warm):
+    """{variant: (status, iter)} of the oracle variants on one case"""
+    import oracle.binding as ob
+    out = {}
+    for name, lib in oracle_variants().items():
+        o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st), libpath=lib)
+        if warm is not None:
+            o.warm_start(warm[0], warm[1])
+        o.solve()
+        out[name] = (int(o.status_val), int(o.info.iter))
+        o.cleanup()
+    return out
+
+
+def judge_case(r, p, st, warm, ytol=1e-8):
+    """The sharp form of "parity with the oracle" for one case.  Returns (ok, why, decided_by_rounding).
+      * (status, iterations) equal to the plain oracle's: x within 1e-8, y within ytol of it (solved cases).
+      * otherwise the case must be one whose count ROUNDING decides -- the oracle's own source, compiled with fused multiply-adds or
+        -Ofast, does not reproduce the plain oracle's (status, iterations) either -- the engine's status must be one an oracle variant
+        reaches, and when both solved the objectives agree to 10 x the case's tolerance (x, y need not: such cases include degenerate
+        problems with several minimisers, where the path decides which one is returned)."""
+    if r["status"][0] == r["status"][1] and r["iter"][0] == r["iter"][1]:
+        if r["status"][1] in (1, 2) and not (r["dx"] <= 1e-8 and r["dy"] <= ytol):
+            return False, "same count, x / y differ: dx %.3e dy %.3e" % (r["dx"], r["dy"]), False
+        return True, "", False
+    var = oracle_outcomes(p, st, warm)
+    plain = (r["status"][1], r["iter"][1])
+    if all(v == plain for v in var.values()):
+        return False, "engine %s vs oracle %s, and the FMA / -Ofast oracles agree with the plain one %s" % ((r["status"][0], r["iter"][0]), plain, var), False
+    if r["status"][0] not in {plain[0]} | {v[0] for v in var.values()}:
+        return False, "engine status %d is reached by no oracle variant (%s, %s)" % (r["status"][0], plain, var), True
+    if r["status"][0] == 1 and r["status"][1] == 1:
+        tol = 10.0 * max(st["eps_abs"], st["eps_rel"])
+        if abs(r["obj"][0] - r["obj"][1]) > tol * max(1.0, abs(r["obj"][1])):
+            return False, "rounding-decided case, but the objectives differ: %r" % (r["obj"],), True
+    return True, "rounding-decided: engine %s, oracle %s, variants %s" % ((r["status"][0], r["iter"][0]), plain, var), True
