@@ -75,6 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
     ap.add_argument("--narrow-rows", type=int, default=1, help="0: Schur assembly with one wavefront per column also for small QPs (A/B)")
     ap.add_argument("--place-panel-wave", type=int, default=1, help="0: every workgroup runs its serial chains on wavefront 0 (A/B of the SIMD placement)")
+    ap.add_argument("--sweep-ranks", type=int, default=0, help="most ranks per sweep of the rank update: 16 or 32 (A/B; 0: library default = 32)")
     ap.add_argument("--ld-align", type=int, default=0, help="leading dimension of the factor panels rounded up to this many doubles (A/B; 0: library default = 16)")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
@@ -357,6 +358,8 @@ def worker(args):
         ctx.set_option("max_slots", args.max_slots)
     if args.ld_align:
         ctx.set_option("ld_align", args.ld_align)
+    if args.sweep_ranks:
+        ctx.set_option("sweep_ranks", args.sweep_ranks)
     if not args.small_workgroups:
         ctx.set_option("small_workgroups", 0)
     if not args.place_panel_wave:

@@ -1021,6 +1021,9 @@ QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *
 #ifndef QP_UNBS
 #define QP_UNBS QP_UNB /* block columns of dense_updown's sweep (dense_updown_big and the coop kernels keep QP_UNB) */
 #endif
+#ifndef QP_UNBS32
+#define QP_UNBS32 16 /* ... of its 32-rank form: 16-column blocks, the LDS tables of 32 ranks x 32 columns x 2 buffers do not fit next to the rest */
+#endif
 #ifndef QP_USQ
 #define QP_USQ 1 /* 1: the owners stage the square L(block s+1 rows, block s columns) in LDS one phase ahead and write the finished
                     diagonal blocks back, so that the panel wave (the serial chain of the sweep) never waits for HBM; costs
@@ -1034,17 +1037,23 @@ QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *
  * throttled owners (QP_ODELAY / QP_OSLEEP), the knock-out timing builds (QP_KO, QP_PROBE_NO_OWNER_TABLE) -- live as a patch in
  * tools/variants/ (tools/build_variant.sh applies it); DESIGN.md section 7 keeps their numbers. */
 #define QP_CWG(U, buf, col) (U).cwg[buf][col]
+template <int K> struct UpdownCfg {
+  static constexpr int NB = (K > 16) ? QP_UNBS32 : QP_UNBS; /* columns per block = per phase */
+  static constexpr int G = (K + 15) / 16;                    /* rank groups of the recurrence: one DPP row (16 lanes) each */
+  static constexpr int KG = K / G;                            /* ranks per group: 8 or 16 */
+};
 template <int RPT, int K>
 struct UpdownLds {           /* [2]: look-ahead double buffers, indexed by block parity */
-  double Ld[2][QP_UNBS][QP_UNBS + 1];
-  double Lsq[QP_USQ ? 2 : 1][QP_USQ ? QP_UNBS : 1][QP_UNBS]; /* [parity][column][row]: the 32 x 32 square of L that the serial chain of the next phase
-                                                               applies a table to (staged by the owners, see the phase loop) */
-  double Wd[2][QP_UNBS][K + 1]; /* running w of the rows of block b (+ the row's substitution accumulator): owners -> panel wave */
-  double cwg[2][QP_UNBS][K][2]; /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast: the two tables, by block parity */
+  static constexpr int NB = UpdownCfg<K>::NB;
+  double Ld[2][NB][NB + 1];
+  double Lsq[QP_USQ ? 2 : 1][QP_USQ ? NB : 1][NB]; /* [parity][column][row]: the NB x NB square of L that the serial chain of the next phase
+                                                      applies a table to (staged by the owners, see the phase loop) */
+  double Wd[2][NB][K + 1];     /* running w of the rows of block b (+ the row's substitution accumulator): owners -> panel wave */
+  double cwg[2][NB][K][2];     /* (-w_j, -gamma) per column and rank, read as one 16-byte broadcast: the two tables, by block parity */
   double stash[RPT][K][64];    /* wavefront 0 parks the running w of its own rows here while it is the panel wave */
   double Wt[K];
-  double dd[2][QP_UNBS];
-  double ys[2][QP_UNBS];        /* fused forward substitution: the solved block of the right-hand side, by block parity */
+  double dd[2][NB];
+  double ys[2][NB];            /* fused forward substitution: the solved block of the right-hand side, by block parity */
   double stash_acc[RPT][64];   /* ... and wavefront 0's own row accumulators while it is the panel wave */
 };
 
@@ -1072,28 +1081,28 @@ template <int R> QPD double qp_row_bcast(double v) { /* ONE v_mov_b64_dpp: row_n
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + R, 0xf, 0xf, true);
 }
 #endif
-/* ranks r = R0 .. R1-1 of one column applied to a row: w_r += c0_r l, l += c1_r w_r, the pair (c0_r, c1_r) living in lane r of
- * every 16-lane row */
+/* ranks r = R0 .. R1-1 of one rank group applied to a row: w_{OFF+r} += c0_r l, l += c1_r w_{OFF+r}, the pair (c0_r, c1_r) living in
+ * lane r of every 16-lane row */
 #ifdef QPALM_EMU
-template <int K, int R0, int R1>
+template <int K, int OFF, int R0, int R1>
 QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) { /* same values, one fiber round instead of 2 (R1 - R0) */
   const int lane = threadIdx.x & 63;
   emu_publish2(cw0, cw1);
-  for (int r = R0; r < R1 && r < K; r++) {
+  for (int r = R0; r < R1 && OFF + r < K; r++) {
     const double c0 = emu_peek((lane & ~15) | r, 0), c1 = emu_peek((lane & ~15) | r, 1);
-    wrow[r] = QP_FMA(c0, l, wrow[r]);
-    l = QP_FMA(c1, wrow[r], l);
+    wrow[OFF + r] = QP_FMA(c0, l, wrow[OFF + r]);
+    l = QP_FMA(c1, wrow[OFF + r], l);
   }
   emu_wave_sync();
 }
 #else
-template <int K, int R0, int R1>
+template <int K, int OFF, int R0, int R1>
 QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) {
-  if constexpr (R0 < R1 && R0 < K) {
+  if constexpr (R0 < R1 && OFF + R0 < K) {
     const double c0 = qp_row_bcast<R0>(cw0), c1 = qp_row_bcast<R0>(cw1);
-    wrow[R0] = QP_FMA(c0, l, wrow[R0]);
-    l = QP_FMA(c1, wrow[R0], l);
-    qp_apply_ranks_dpp<K, R0 + 1, R1>(cw0, cw1, wrow, l);
+    wrow[OFF + R0] = QP_FMA(c0, l, wrow[OFF + R0]);
+    l = QP_FMA(c1, wrow[OFF + R0], l);
+    qp_apply_ranks_dpp<K, OFF, R0 + 1, R1>(cw0, cw1, wrow, l);
   }
 }
 #endif
@@ -1104,18 +1113,31 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
 #define QP_RECUR_DPP 1
 #endif
 
+/* ---------------------------------------------------------------------------------------------
+ * K = 32 (round 4): TWICE the ranks per pass over the panel = half the panel traffic per rank.  Two things make that fit:
+ *  - Registers: a thread keeps the 32 running values of ONE row (RPT = 1: 64 VGPRs, what two rows of 16 took), so the rows are
+ *    handled in PASSES of QP_T rows.  Pass p owns rows [R0, R1) = [p QP_T, (p+1) QP_T): first its rows receive the tables of all
+ *    earlier columns [J0, R0) -- produced by the earlier passes, exported to HBM (512 KB for n = 1000: L2 / Infinity Cache),
+ *    applied by ALL wavefronts with no serial chain at all ("rectangle") --, then the look-ahead sweep runs on the pass's own
+ *    triangle, columns [R0, R1), and exports its tables.  Every entry of L is still read and written once per sweep.
+ *  - The recurrence: the 32 ranks of a column are two groups of 16 handled one after the other in the same lanes (lane & 15 =
+ *    rank within the group; the second group starts from the pivot the first one leaves).  Per entry this is the SAME sequence
+ *    of operations as two 16-rank sweeps, so the factor is bit-identical to what the 16-rank form produces.
+ * ------------------------------------------------------------------------------------------- */
 template <int RPT, int K>
 #ifndef QP_NI_UPDOWN
 #define QP_NI_UPDOWN QPNI
 #endif
-/* a real function (own register allocation, see qpalm_device.h): plain pointer arguments, re-typed inside */
+/* a real function (own register allocation, see qpalm_device.h): plain pointer arguments, re-typed inside.
+ * Ranks [rk0, rk0 + rkn) of the list "entering rows, then leaving rows" are applied, K per sweep. */
 QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *Atss_, const int n_, const int ld_,
                                double *L_, double *Dg_, double *Wst_, const int *cols_, int n_up_,
                                const int *cols_dn_, int n_dn_, QpShared *S_, char *lds, int64_t *tdbg_, int pre_jmin_ = -1,
-                               double *fs_ = nullptr) {
+                               double *fs_ = nullptr, int rk0_ = 0, int rkn_ = 0x7fffffff) {
   /* arguments of a real function arrive in VGPRs; these are wave-uniform: back to SGPRs, so that the
    * loops they bound are scalar loops (not exec-mask loops) and v_readlane indices are scalars */
   const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), n_up = QP_UNIFORM(n_up_), n_dn = QP_UNIFORM(n_dn_);
+  const int rk0 = QP_UNIFORM(rk0_), rkn = QP_UNIFORM(rkn_);
   /* pre_jmin >= 0: ONE rank whose dense vector the caller has already written to Wst[0 .. n) (first nonzero at
    * pre_jmin), sign +1 if n_up == 1 else -1: the trailing update of a KKT row addition / deletion */
   const int pre_jmin = QP_UNIFORM(pre_jmin_);
@@ -1129,18 +1151,26 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   const qp_gdouble *Atss = (const qp_gdouble *)Atss_;
   qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_, *Wst = (qp_gdouble *)Wst_;
   QpShared &S = *S_; /* static LDS of the kernel, reached through a generic pointer (one small reduction) */
-  static_assert(K == 8 || K == 16, "rank block: one DPP row, groups of eight ranks");
+  static_assert(K == 8 || K == 16 || K == 32, "rank groups of one DPP row (16 lanes), eight ranks at a time");
+  static_assert(K <= QPG_KWST, "the staging area holds QPG_KWST dense update vectors");
   typedef UpdownLds<RPT, K> UpdownLdsT;
   UpdownLdsT QP_LDS_AS &U = *QP_LDS_ARG(UpdownLdsT, lds);
-  static_assert(sizeof(UpdownLds<RPT, K>) <= QPG_LDS_DEFAULT, "update scratch must fit the dynamic LDS (lds_bytes >= QPG_LDS_DEFAULT)");
-  const int NB = QP_UNBS;
+  static_assert(sizeof(UpdownLds<RPT, K>) <= ((RPT == 1) ? QP_LDS_BUDGET : QPG_LDS_DEFAULT), "update scratch must fit the dynamic LDS (the 256-thread instance only ever runs RPT = 1)");
+  constexpr int NB = UpdownCfg<K>::NB, G = UpdownCfg<K>::G, KG = UpdownCfg<K>::KG;
+  constexpr int PROWS = QP_T * RPT; /* rows per pass */
+  constexpr bool MP = (K > 16);     /* several passes (the forms with at most 16 ranks run with RPT = all rows of the factor / QP_T: one pass) */
+  static_assert(PROWS % NB == 0, "passes start on block boundaries");
   /* wavefront numbering rotated so that "wavefront 0" below (panel wave, owner of the first rows) is the wavefront
    * qp_place_panel_wave picked for this workgroup; rows are owned by the ROTATED thread id throughout the sweep */
   const int lane = threadIdx.x & 63, wid = QP_UNIFORM((int)((threadIdx.x >> 6) - S.panel_wave) & (QP_NW - 1)), tid = wid * 64 + lane;
-  const int nr = n_up + n_dn;
-  for (int r0 = 0; r0 < nr; r0 += K) {
-    const int kk = (nr - r0 < K) ? (nr - r0) : K;
-    const bool fuse = fuse_any && (r0 + K >= nr);
+  const int nr_all = n_up + n_dn;
+  const int rk1 = (rkn < nr_all - rk0) ? (rk0 + rkn) : nr_all; /* ranks [rk0, rk1) */
+  qp_gdouble *dummy = Wst + (size_t)QPG_KWST * n;
+  qp_gdouble *Tab = dummy + QPG_DUMMY + QPG_HSTASH; /* exported tables of a multi-pass sweep: [column][K][2] */
+  const int npass = MP ? (n + PROWS - 1) / PROWS : 1;
+  for (int r0 = rk0; r0 < rk1; r0 += K) {
+    const int kk = (rk1 - r0 < K) ? (rk1 - r0) : K;
+    const bool fuse = fuse_any && (r0 + K >= nr_all);
     __syncthreads();
     long long tq0 = QP_CLOCK();
     int jmin = n;
@@ -1159,44 +1189,161 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
     } else jmin = (pre_jmin < n) ? pre_jmin : n - 1;
     if (fuse) jmin = 0;
     jmin = QP_UNIFORM(block_imin(S, jmin)); /* same value in every lane: keep the block loops scalar */
-    double w[RPT][K];
+    /* lane r of every 16-lane row of the panel wave carries alpha_r and 1/alpha_r of rank 16 g + r (QP_RECUR_DPP; else lane r, G = 1);
+     * they run on through the passes */
+    double alpha[G], ialpha[G], sg[G];
+    const int rl = QP_RECUR_DPP ? (lane & 15) : lane;
 #pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-      const int i = tid * RPT + rr; /* adjacent rows per thread: finished rows retire whole wavefronts */
-#pragma unroll
-      for (int r = 0; r < K; r++) w[rr][r] = (i < n && r < kk) ? Wst[(size_t)r * n + i] : 0.0;
+    for (int g = 0; g < G; g++) {
+      alpha[g] = 1.0; ialpha[g] = 1.0;
+      sg[g] = (16 * g + rl < kk) ? ((r0 + 16 * g + rl < n_up) ? 1.0 : -1.0) : 0.0;
     }
-    double acc[RPT]; /* fused forward substitution: b_i - sum over the finished columns of l_ij y_j */
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; acc[rr] = (fuse && i < n) ? fs[i] : 0.0; }
-    double alpha = 1.0, ialpha = 1.0; /* lane r of the panel wave carries alpha_r and 1/alpha_r (QP_RECUR_DPP: lane r of each of its 16-lane rows) */
-    const int rl = QP_RECUR_DPP ? (lane & 15) : lane, grank = r0 + rl;
-    const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
     const int J0 = (jmin / NB) * NB;
     if (tid == 0) {
       const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1;
       tdbg[QPG_CNT_SWEEPS] += 1;
       tdbg[QPG_CNT_SWEEP_ENTRIES] += (long long)(n - J0) * (n - J0 - 1) / 2 + (n - J0); /* strict lower part of columns J0.. + pivots */
     }
-    const int nblk = (n - J0 + NB - 1) / NB;
-    qp_gdouble *dummy = Wst + (size_t)QPG_KMAX * n;
+    for (int pass = 0; pass < npass; pass++) {
+    const int R0 = pass * PROWS;                          /* this pass: rows [R0, R1), its triangle = columns [Js, R1) */
+    const int R1 = (!MP || n - R0 < PROWS) ? n : R0 + PROWS;
+    const int Js = (J0 > R0) ? J0 : R0;
+    if (Js >= R1) continue;                               /* the update vectors are zero on these rows and nothing earlier touches them */
+    const bool last_pass = (R1 >= n);
+    const int rlim = last_pass ? ld : R1;                 /* rows n..ld-1 (padding of the panel) ride along in the last pass */
+    if (MP && npass > 1) __syncthreads();                 /* the previous pass's last table export / LDS buffers */
+    double w[RPT][K];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+      const int i = R0 + tid * RPT + rr; /* adjacent rows per thread: finished rows retire whole wavefronts */
+#pragma unroll
+      for (int r = 0; r < K; r++) w[rr][r] = (i < R1 && r < kk) ? Wst[(size_t)r * n + i] : 0.0;
+    }
+    double acc[RPT]; /* fused forward substitution: b_i - sum over the finished columns of l_ij y_j */
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) { const int i = R0 + tid * RPT + rr; acc[rr] = (fuse && i < R1) ? fs[i] : 0.0; }
+    /* One block of a finished table (buffer `tb` of U.cwg, ys in U.ys[tb]) applied to this thread's rows, columns Jc .. Jc + NB - 1:
+     * one column per iteration.  Branch-free body: rows that do not take part read/write a private dummy cell (column stride 0);
+     * the column QD ahead is prefetched into a register queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four
+     * ranks at a time.  Register budget <= 128 VGPRs so that two workgroups share a CU.  The RPT adjacent rows of a thread are
+     * one access group: 16-byte loads/stores (RPT even), one address and one liveness per thread. */
+    auto apply_table = [&](const int tb, const int Jc, const bool ok) QP_ALWAYS_INLINE {
+      constexpr int QD = (K > 16) ? 2 * QP_TQD : QP_TQD; /* one row per thread, 8-byte accesses: twice the columns in flight */
+      static_assert(NB % QD == 0, "queue depth divides the block");
+      const int i0 = R0 + tid * RPT;
+      qp_gdouble *rowp = ok ? (L + (size_t)Jc * ld + i0) : (dummy + tid * RPT);
+      const size_t cstride = ok ? (size_t)ld : 0;
+      double q[QD][RPT];
+#pragma unroll
+      for (int cc = 0; cc < QD; cc++) qp_load_rows_nt<RPT>(rowp + (size_t)cc * cstride, q[cc]);
+      auto group = [&](const int c0) QP_ALWAYS_INLINE {
+#pragma unroll
+        for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
+          int c1 = c0 + u;
+          QP_OPAQUE(c1); /* addresses are recomputed from c1: no per-slot induction pointers (VGPR budget) */
+          double l[RPT];
+          const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
+#pragma unroll
+          for (int rb = 0; rb < K; rb += 4) {
+            if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
+            double cf[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              cf[r][0] = (rb + r < K) ? QP_CWG(U, tb, c1)[rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? QP_CWG(U, tb, c1)[rb + r][1] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              if (rb + r < K) {
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr++) {
+                  w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
+                  l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
+                }
+              }
+            }
+            QP_SCHED_BARRIER();
+          }
+          qp_store_rows_nt<RPT>(rowp + (size_t)c1 * cstride, l);
+          if (fuse) { /* column Jc + c1 is final for these rows: its term of the forward substitution */
+            const double yv = U.ys[tb][c1];
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
+          }
+          QP_SCHED_BARRIER();
+          qp_load_rows_nt<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
+          QP_SCHED_BARRIER();
+        }
+      };
+      group(0); /* peeled, see the panel wave's loop */
+#pragma unroll 1
+      for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+    };
+    /* table block `tb` of U.cwg (columns Jc .. Jc + NB - 1, complete) to the export area: a later pass applies it to its rows */
+    auto export_table = [&](const int tb, const int Jc, const int t0, const int nt) QP_ALWAYS_INLINE {
+      const qp_pair QP_LDS_AS *src = (const qp_pair QP_LDS_AS *)&U.cwg[tb][0][0][0];
+      for (int e = t0; e < NB * K; e += nt) {
+        const qp_pair v = src[e];
+        Tab[((size_t)Jc * K + e) * 2] = v.x; Tab[((size_t)Jc * K + e) * 2 + 1] = v.y;
+      }
+    };
+    if constexpr (MP) if (R0 > J0) {
+      /* ===== rectangle: the tables of the earlier passes' columns [J0, R0) on this pass's rows, every wavefront, no serial chain.
+       * Block b + 1 of the export area travels through registers into U.cwg[(b + 1) & 1] (+ y of its columns into U.ys) while
+       * block b is applied: its load latency runs under the FMAs. ========================================================== */
+      const int nrb = (R0 - J0) / NB;
+      const int i0 = R0 + tid * RPT;
+      const bool ok = (i0 < rlim);
+      constexpr int NE = (NB * K + QP_T - 1) / QP_T;
+      qp_pair stg[NE];
+      double ystg = 0.0;
+      auto tab_load = [&](const int b) QP_ALWAYS_INLINE {
+        const int Jc = J0 + b * NB;
+#pragma unroll
+        for (int q = 0; q < NE; q++) {
+          const int e = tid + q * QP_T;
+          if (e < NB * K) { stg[q].x = Tab[((size_t)Jc * K + e) * 2]; stg[q].y = Tab[((size_t)Jc * K + e) * 2 + 1]; }
+        }
+        if (fuse && tid < NB) ystg = fs[Jc + tid];
+      };
+      auto tab_store = [&](const int b) QP_ALWAYS_INLINE {
+        qp_pair QP_LDS_AS *dst = (qp_pair QP_LDS_AS *)&U.cwg[b & 1][0][0][0];
+#pragma unroll
+        for (int q = 0; q < NE; q++) {
+          const int e = tid + q * QP_T;
+          if (e < NB * K) dst[e] = stg[q];
+        }
+        if (fuse && tid < NB) U.ys[b & 1][tid] = ystg;
+      };
+      tab_load(0);
+      tab_store(0);
+      __syncthreads();
+      for (int b = 0; b < nrb; b++) {
+        if (b + 1 < nrb) tab_load(b + 1);
+        if (ok) apply_table(b & 1, J0 + b * NB, true);
+        if (b + 1 < nrb) tab_store(b + 1);
+        __syncthreads();
+      }
+    }
+    const int nblk = (R1 - Js + NB - 1) / NB;
     /* prologue: rows of block 0 to the hand-over buffer, diagonal block 0 to LDS */
     {
-      const int jb0 = (n - J0 < NB) ? (n - J0) : NB;
+      const int jb0 = (R1 - Js < NB) ? (R1 - Js) : NB;
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) {
-        const int i = tid * RPT + rr;
-        if (i >= J0 && i < J0 + jb0) { /* block 0 */
+        const int i = R0 + tid * RPT + rr;
+        if (i >= Js && i < Js + jb0) { /* block 0 */
 #pragma unroll
-          for (int r = 0; r < K; r++) U.Wd[0][i - J0][r] = w[rr][r];
-          U.Wd[0][i - J0][K] = acc[rr];
+          for (int r = 0; r < K; r++) U.Wd[0][i - Js][r] = w[rr][r];
+          U.Wd[0][i - Js][K] = acc[rr];
         }
       }
       for (int e = tid; e < jb0 * jb0; e += QP_T) {
         const int c1 = e / jb0, c = e % jb0;
-        if (c > c1) U.Ld[0][c][c1] = L[(size_t)(J0 + c1) * ld + (J0 + c)];
+        if (c > c1) U.Ld[0][c][c1] = L[(size_t)(Js + c1) * ld + (Js + c)];
       }
-      if (tid < jb0) U.dd[0][tid] = Dg[J0 + tid];
+      if (tid < jb0) U.dd[0][tid] = Dg[Js + tid];
       if (wid == 0) {
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++)
@@ -1209,82 +1356,26 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[0] += tq1 - tq0; tq0 = tq1; }
     __syncthreads();
     for (int s = 0; s < nblk; s++) {
-      const int J = J0 + s * NB, Jp = J - NB, Jn = J + NB;
-      const int jb = (n - J < NB) ? (n - J) : NB;
-      const int jbn = (n - Jn < NB) ? ((n - Jn > 0) ? (n - Jn) : 0) : NB; /* 0 when block s is the last one */
+      const int J = Js + s * NB, Jp = J - NB, Jn = J + NB;
+      const int jb = (R1 - J < NB) ? (R1 - J) : NB;
+      const int jbn = (R1 - Jn < NB) ? ((R1 - Jn > 0) ? (R1 - Jn) : 0) : NB; /* 0 when block s is the last one of the pass */
       const int cur = s & 1, prv = cur ^ 1;
       long long tpe = QP_CLOCK();
-      const bool own_live0 = (64 * RPT - 1 >= Jn); /* wavefront 0 still owns rows the owners work on */
+      const bool own_live0 = (R0 + 64 * RPT - 1 >= Jn); /* wavefront 0 still owns rows the owners work on */
       auto owner_block = [&]() QP_ALWAYS_INLINE {
         /* ===== owners: table s-1 on the rows below block s, then the rows of block s+1 to the hand-over buffer ========= */
         const long long tt0 = QP_CLOCK();
         bool any = false;
 #pragma unroll
-        for (int rr = 0; rr < RPT; rr++) { const int i = tid * RPT + rr; any = any || (i >= Jn && i < n); }
+        for (int rr = 0; rr < RPT; rr++) { const int i = R0 + tid * RPT + rr; any = any || (i >= Jn && i < R1); }
         if (s > 0 && any) {
-          /* One column per iteration.  Branch-free body: rows that are not below the block read/write
-           * a private dummy cell (column stride 0); the column QD ahead is prefetched into a register
-           * queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four ranks at a time.
-           * Register budget <= 128 VGPRs so that two workgroups share a CU. */
-          constexpr int QD = QP_TQD;
-          /* the RPT adjacent rows of a thread are one access group: 16-byte loads/stores (RPT even),
-           * one address and one liveness per thread.  Rows n..ld-1 are padding of the panel (ld is a
-           * multiple of 8): they are carried along (w = 0 there, nobody reads them). */
-          const int i0 = tid * RPT;
-          const bool ok = (i0 >= Jn && i0 < ld);
-          qp_gdouble *rowp = ok ? (L + (size_t)Jp * ld + i0) : (dummy + tid * RPT);
-          const size_t cstride = ok ? (size_t)ld : 0;
-          double q[QD][RPT];
-#pragma unroll
-          for (int cc = 0; cc < QD; cc++) qp_load_rows_nt<RPT>(rowp + (size_t)cc * cstride, q[cc]);
-          auto group = [&](const int c0) QP_ALWAYS_INLINE {
-#pragma unroll
-            for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
-              int c1 = c0 + u;
-              QP_OPAQUE(c1); /* addresses are recomputed from c1: no per-slot induction pointers (VGPR budget) */
-              double l[RPT];
-              const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
-#pragma unroll
-              for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
-#pragma unroll
-              for (int rb = 0; rb < K; rb += 4) {
-                if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
-                double cf[4][2];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                  cf[r][0] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][0] : 0.0; cf[r][1] = (rb + r < K) ? QP_CWG(U, prv, c1)[rb + r][1] : 0.0;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                  if (rb + r < K) {
-#pragma unroll
-                    for (int rr = 0; rr < RPT; rr++) {
-                      w[rr][rb + r] = QP_FMA(cf[r][0], l[rr], w[rr][rb + r]);
-                      l[rr] = QP_FMA(cf[r][1], w[rr][rb + r], l[rr]);
-                    }
-                  }
-                }
-                QP_SCHED_BARRIER();
-              }
-              qp_store_rows_nt<RPT>(rowp + (size_t)c1 * cstride, l);
-              if (fuse) { /* column Jp + c1 is final for these rows: its term of the forward substitution */
-                const double yv = U.ys[prv][c1];
-#pragma unroll
-                for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
-              }
-              QP_SCHED_BARRIER();
-              qp_load_rows_nt<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
-              QP_SCHED_BARRIER();
-            }
-          };
-          group(0); /* peeled, see the panel wave's loop */
-#pragma unroll 1
-          for (int c0 = QD; c0 < NB; c0 += QD) group(c0);
+          const int i0 = R0 + tid * RPT;
+          apply_table(prv, Jp, i0 >= Jn && i0 < rlim);
         }
         /* rows of block s+1 to the hand-over buffer of the next phase */
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
-          const int i = tid * RPT + rr;
+          const int i = R0 + tid * RPT + rr;
           if (i >= Jn && i < Jn + jbn) {
 #pragma unroll
             for (int r = 0; r < K; r++) U.Wd[prv][i - Jn][r] = w[rr][r];
@@ -1347,6 +1438,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                     l = QP_FMA(cg[r], wrow[rb + r], l);
                   }
                 }
+                if (K > 16) QP_SCHED_BARRIER(); /* 32 ranks: one group of eight pairs in registers at a time */
               }
               rowp[(size_t)c1 * cstride] = l;
               if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
@@ -1383,38 +1475,53 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             for (int r = 0; r < K; r++) wt[r] = wrow[r];
           }
           QP_WAVE_SYNC();
-          /* rank-indexed scalars: lane = rank (lanes >= kk carry w = 0 => gamma = 0: exact no-ops) */
+          /* rank-indexed scalars: lane = rank within its group (lanes >= kk carry w = 0 => gamma = 0: exact no-ops).  The groups of
+           * 16 ranks follow each other in the same lanes; group g starts from the pivot group g-1 leaves. */
           const int rk = QP_RECUR_DPP ? (ln & 15) : ln;
-          const double wv = (rk < kk) ? wt[rk & (K - 1)] : 0.0;
-          if (QP_PANEL_TIMING == 2) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
-          const double d0 = qp_readlane(dreg, c1);
-          const double p = sg * wv * wv * ialpha;
-          double incl = p;
-          if (K > 1) incl += qp_row_shr<1>(incl);
-          if (K > 2) incl += qp_row_shr<2>(incl);
-          if (K > 4) incl += qp_row_shr<4>(incl);
-          if (K > 8) incl += qp_row_shr<8>(incl);
-          const double excl = qp_row_shr<1>(incl);
-          const double dnew = d0 + incl, dprev = d0 + excl;
-          const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
-          const double gam = -sg * wv * ialpha * rdn;
-          if (QP_PANEL_TIMING == 2) { double gg = gam; QP_OPAQUE_V(gg); const long long t = QP_CLOCK(); if (lane == 0) tdbg[9] += t - tc0; tc0 = t; }
-          if (ln < K) { QP_CWG(U, cur, c1)[ln][0] = -wv; QP_CWG(U, cur, c1)[ln][1] = -gam; } /* stored negated: plain FMAs below */
-          alpha = alpha * dnew * rdp;
-          ialpha = ialpha * dprev * rdn;
-          { /* final pivot of the column = value after the last rank */
-            const double dfin = qp_readlane(dnew, kk - 1);
-            if (ln == c1) dreg = dfin;
+          double d0 = qp_readlane(dreg, c1);
+          double nwv[G], ngam[G];
+#pragma unroll
+          for (int g = 0; g < G; g++) {
+            const int kkg = (kk - 16 * g < KG) ? (kk - 16 * g) : KG; /* ranks of this group in this sweep (wave-uniform; <= 0: none) */
+            nwv[g] = 0.0; ngam[g] = 0.0;
+            if (g > 0 && kkg <= 0) continue;
+            const double wv = (rk < kkg) ? wt[(16 * g + rk) & (K - 1)] : 0.0;
+            if (QP_PANEL_TIMING == 2 && g == 0) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
+            const double p = sg[g] * wv * wv * ialpha[g];
+            double incl = p;
+            if (KG > 1) incl += qp_row_shr<1>(incl);
+            if (KG > 2) incl += qp_row_shr<2>(incl);
+            if (KG > 4) incl += qp_row_shr<4>(incl);
+            if (KG > 8) incl += qp_row_shr<8>(incl);
+            const double excl = qp_row_shr<1>(incl);
+            const double dnew = d0 + incl, dprev = d0 + excl;
+            const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
+            const double gam = -sg[g] * wv * ialpha[g] * rdn;
+            if (ln < KG) { QP_CWG(U, cur, c1)[16 * g + ln][0] = -wv; QP_CWG(U, cur, c1)[16 * g + ln][1] = -gam; } /* stored negated: plain FMAs below */
+            /* a rank whose vector is zero in this column leaves its alpha alone: d_new / d_prev is exactly 1 there, d * rcp(d) is not.
+             * (Columns above a rank's first nonzero are then exact no-ops: the result does not depend on where a sweep starts or on
+             * how the ranks are grouped into sweeps.) */
+            alpha[g] = (wv == 0.0) ? alpha[g] : alpha[g] * dnew * rdp;
+            ialpha[g] = (wv == 0.0) ? ialpha[g] : ialpha[g] * dprev * rdn;
+            d0 = qp_readlane(dnew, kkg - 1); /* pivot of the column after this group's last rank */
+            nwv[g] = -wv; ngam[g] = -gam;
           }
+          if (QP_PANEL_TIMING == 2) { double gg = ngam[0]; QP_OPAQUE_V(gg); const long long t = QP_CLOCK(); if (lane == 0) tdbg[9] += t - tc0; tc0 = t; }
+          if (ln == c1) dreg = d0; /* final pivot of the column = value after the last rank */
           if (!QP_RECUR_DPP) QP_WAVE_SYNC();
           /* rows of the block: lane = row.  Rows <= c1 are finished, their registers may be
            * overwritten freely, so no selects: w_r -= w_j l ; l -= gamma w_r  (2 FMAs per rank) */
           if (QP_RECUR_DPP) {
             double l = lcur;
-            qp_apply_ranks_dpp<K, 0, 8>(-wv, -gam, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
-            if (K > 8 && kk > 8) qp_apply_ranks_dpp<K, 8, 16>(-wv, -gam, wrow, l);
+            qp_apply_ranks_dpp<K, 0, 0, 8>(nwv[0], ngam[0], wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
+            if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16>(nwv[0], ngam[0], wrow, l);
+            if constexpr (G > 1) {
+              if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8>(nwv[1], ngam[1], wrow, l);
+              if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16>(nwv[1], ngam[1], wrow, l);
+            }
             if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;
           } else {
+            static_assert(QP_RECUR_DPP || G == 1, "the LDS form of the recurrence handles one rank group");
             double l = lcur;
             /* the first eight entries come back from LDS together; with more than eight ranks an entry's registers are refilled with
              * the entry eight ranks further right after its two FMAs, so that the second group's LDS latency runs under the first
@@ -1508,17 +1615,20 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           }
         }
         if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
+        if (MP && !last_pass && s > 0) export_table(prv, Jp, t0, nt); /* table s-1 is complete: the later passes' rows need it */
       }
       __syncthreads();
       if (QP_PANEL_TIMING == 1 && tid == 0) tdbg[11] += QP_CLOCK() - tpe;
     }
     if (QP_USQ) { /* the last diagonal block is still in LDS */
-      const int sl = nblk - 1, Jl = J0 + sl * NB, jbl = n - Jl;
+      const int sl = nblk - 1, Jl = Js + sl * NB, jbl = R1 - Jl;
       for (int e = tid; e < NB * NB; e += QP_T) {
         const int c1 = e / NB, c = e % NB;
         if (c > c1 && c < jbl) L[(size_t)(Jl + c1) * ld + (Jl + c)] = U.Ld[sl & 1][c][c1];
       }
     }
+    if (MP && !last_pass) export_table((nblk - 1) & 1, Js + (nblk - 1) * NB, tid, QP_T); /* the pass's last table */
+    } /* passes */
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[7] += tq1 - tq0; tq0 = tq1; }
   }
   __syncthreads();
@@ -1578,13 +1688,13 @@ QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const in
     const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
     const double gam = -sg * wv * ialpha * rdn;
     if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; }
-    alpha = alpha * dnew * rdp;
-    ialpha = ialpha * dprev * rdn;
+    alpha = (wv == 0.0) ? alpha : alpha * dnew * rdp; /* zero in this column: exactly unchanged (see dense_updown) */
+    ialpha = (wv == 0.0) ? ialpha : ialpha * dprev * rdn;
     { const double dfin = qp_readlane(dnew, kk - 1); if (ln == c1) dreg = dfin; }
     if (QP_PANEL_DPP) {
       double l = lcur;
-      qp_apply_ranks_dpp<K, 0, 8>(-wv, -gam, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
-      if (K > 8 && kk > 8) qp_apply_ranks_dpp<K, 8, 16>(-wv, -gam, wrow, l);
+      qp_apply_ranks_dpp<K, 0, 0, 8>(-wv, -gam, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
+      if (K > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16>(-wv, -gam, wrow, l);
       if (ln > c1 && ln < jb) U.Ld[ln][c1] = l;
     } else {
       QP_WAVE_SYNC();

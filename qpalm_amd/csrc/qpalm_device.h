@@ -30,6 +30,17 @@
 #ifndef QP_KSEL
 #define QP_KSEL(RPT) ((RPT) <= 2 ? 16 : 8)
 #endif
+/* which instances of k_solve<RPT> also carry the 32-rank multi-pass sweep dense_updown<1, 32> (passes of QP_T rows): the 512-thread
+ * instance up to 1024 rows (RPT 1 and 2: one or two passes) */
+#ifndef QP_K32
+#ifdef QPALM_EMU
+#define QP_K32(RPT) ((RPT) >= 1 && (RPT) <= 2) /* the test build (any block size) exercises it too */
+#define QP_LDS_BUDGET QPG_LDS_DEFAULT
+#else
+#define QP_K32(RPT) (QP_T >= 512 && (RPT) >= 1 && (RPT) <= 2)
+#define QP_LDS_BUDGET ((QP_T >= 512) ? QPG_LDS_DEFAULT : 38912)
+#endif
+#endif
 #define QPD __device__ __forceinline__
 #define QPN __device__ __forceinline__
 /* Which phases of the iteration are real calls (own register allocation, fewer values live across them in the loop body) instead

@@ -257,7 +257,15 @@ QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, doub
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
   if constexpr (RPT == 0) dense_updown_big<16>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin);
-  else dense_updown<RPT, QP_KSEL(RPT)>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin, fs);
+  else if constexpr (QP_K32(RPT)) {
+    /* up to 32 ranks per sweep: the multi-pass form takes the ranks in sweeps of 32 as long as more than 16 are left (17..32 ranks:
+     * one sweep over the panel instead of two), the 16-rank form the rest.  Bit-identical factors whichever form runs. */
+    const int nr = n_up + n_dn;
+    int n32 = 0;
+    if (V.sweep_ranks >= 32 && pre_jmin < 0 && nr > 16) n32 = (nr % 32 > 16 || nr % 32 == 0) ? nr : nr - nr % 32;
+    if (n32 > 0) dense_updown<1, 32>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, -1, (n32 == nr) ? fs : nullptr, 0, n32);
+    if (n32 < nr) dense_updown<RPT, QP_KSEL(RPT)>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin, fs, n32, nr - n32);
+  } else dense_updown<RPT, QP_KSEL(RPT)>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin, fs);
 }
 
 /* =============================================================================================

@@ -82,7 +82,7 @@ typedef struct {
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
   int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, place_panel_wave, narrow_rows;
-  int32_t offload, offload_pad; /* coop mode: 1 = dev_solve suspends at its linear-algebra site for factorisations and Newton solves, 2 = for rank updates too */
+  int32_t offload, sweep_ranks; /* sweep_ranks: most ranks one sweep of the rank update applies (16, or 32 = the multi-pass form of dense_updown, the default).  coop mode: 1 = dev_solve suspends at its linear-algebra site for factorisations and Newton solves, 2 = for rank updates too */
   int32_t kkt, nfac; /* kkt != 0: FACTORIZE_KKT, the factor slots hold the (n+m) x (n+m) KKT panel; nfac = rows of a factor slot
                         (n, or n + m in KKT mode); ld = its leading dimension */
   /* problem data.  A: CSC m x n.  At: CSC of A' (n x m) with the permutation into A's entries.
@@ -111,15 +111,18 @@ typedef struct {
   double *kkt_sol, *kkt_rhs, *kkt_tmp; /* [B][n+m] sol_kkt / rhs_kkt of the KKT path (qpalm.c:241-242) + scratch; NULL in Schur mode */
   int32_t *nq, *mq;   /* [B] per-QP dimensions (<= n, m: members of a mixed-size batch are padded to the batch strides); NULL = uniform */
   int32_t *kkt_state; /* [B][m] 0 unit diagonal, 1 row present, 2 deleted by row_del (solver_interface.c:151-156,226-235) */
-  double *Wst; /* [nslots][wst_stride]: QPG_KMAX*n staging for rank-update vectors + a dummy row area */
+  double *Wst; /* [nslots][wst_stride]: staging of the rank-update vectors, dummy cells, exported tables (QPG_WST_STRIDE) */
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */
   int32_t *queue; /* [64 + QPG_CU_KEYS]: [0] work-queue head; [64 + key] workgroups that have arrived on compute unit `key` in this launch */
 } qpg_view;
 
-#define QPG_KMAX 16
+#define QPG_KMAX 16 /* ranks per sweep of the large-factor and coop-mode sweeps */
+#define QPG_KWST 32 /* dense update vectors the staging area of a slot holds = most ranks per sweep of dense_updown */
 #define QPG_DUMMY 4096 /* doubles per slot that masked-off rows load from / store to */
-#define QPG_HSTASH 4096 /* doubles per slot where the helper wave of the update sweep parks its own running w */
+#define QPG_HSTASH 4096 /* doubles per slot of scratch behind the dummy area (coop mode: the state of a grid update) */
+/* a slot of Wst: [QPG_KWST][rows] update vectors | QPG_DUMMY | QPG_HSTASH | [rows][QPG_KWST][2] exported (-w, -gamma) tables of a multi-pass sweep */
+#define QPG_WST_STRIDE(rows) ((size_t)QPG_KWST * (rows) + QPG_DUMMY + QPG_HSTASH + (size_t)2 * QPG_KWST * (rows))
 
 #endif

@@ -22,7 +22,7 @@ def _campaign(ctx, seed, count, n_lo, n_hi, force=None, ytol_big=1e-5):
     bad, soft = [], []
     for it, p, st, warm, meta in cases(seed, count, n_lo, n_hi, force):
         r = run_case(ctx, p, st, warm)
-        ok, why, rounding = judge_case(r, p, st, warm, ytol_big if st["sigma_init"] >= 1e3 else 1e-8)
+        ok, why, rounding = judge_case(r, p, st, warm, ytol_big if st["sigma_init"] >= 1e3 else 1e-8, ctx)
         if not ok:
             bad.append((seed, it, meta, {k: st[k] for k in ("factorization_method", "sigma_init", "scaling", "proximal")}, why))
         elif rounding:
@@ -63,5 +63,5 @@ def test_round3_mismatches_are_rounding_decided(ctx, seed, case, n_lo, n_hi):
         if it != case:
             continue
         r = run_case(ctx, p, st, warm)
-        ok, why, rounding = judge_case(r, p, st, warm, 1e-5 if st["sigma_init"] >= 1e3 else 1e-8)
+        ok, why, rounding = judge_case(r, p, st, warm, 1e-5 if st["sigma_init"] >= 1e3 else 1e-8, ctx)
         assert ok, (seed, case, meta, why, r)
