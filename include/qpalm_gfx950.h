@@ -149,7 +149,15 @@ int  qpg_batch_set_problem(qpg_batch *bt, qpg_int idx, const qpg_int *Qp, const 
 int  qpg_batch_set_problem_sized(qpg_batch *bt, qpg_int idx, qpg_int n, qpg_int m, const qpg_int *Qp, const qpg_int *Qi,
                                  const qpg_float *Qx, const qpg_int *Ap, const qpg_int *Ai, const qpg_float *Ax,
                                  const qpg_float *q, qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
-int  qpg_batch_setup(qpg_batch *bt);                               /* upload + Ruiz scaling on device */
+/* qpg_batch_set_problem_sized for members first .. first + count - 1 in ONE call (entry k of every array = member first + k; n / m
+ * NULL: every member has the batch's dimensions; c NULL: zero constants): the per-QP host work of qpalm_setup -- deep copies,
+ * sorted CSC, the A' pattern (src/qpalm.c:128-144, iteration.c:81) -- runs on host threads (QPALM_HOST_THREADS, default: all,
+ * at most 64).  No reference counterpart (the reference sets up one QP per call). */
+int  qpg_batch_set_problems(qpg_batch *bt, qpg_int first, qpg_int count, const qpg_int *n, const qpg_int *m,
+                            const qpg_int *const *Qp, const qpg_int *const *Qi, const qpg_float *const *Qx,
+                            const qpg_int *const *Ap, const qpg_int *const *Ai, const qpg_float *const *Ax,
+                            const qpg_float *const *q, const qpg_float *c, const qpg_float *const *bmin, const qpg_float *const *bmax);
+int  qpg_batch_setup(qpg_batch *bt);                               /* upload (threads pack, DMA from page-locked staging) + Ruiz scaling on device */
 int  qpg_batch_warm_start(qpg_batch *bt, const qpg_float *x, const qpg_float *y); /* [B][n], [B][m] or NULL */
 int  qpg_batch_warm_start_last(qpg_batch *bt);                     /* qpalm_warm_start(work, last x, last y) of every QP, from HBM (no host copy) */
 int  qpg_batch_solve(qpg_batch *bt);                               /* run every QP to termination */

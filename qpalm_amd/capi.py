@@ -80,6 +80,8 @@ def load(path=None):
     L.qpg_batch_create.argtypes = [C.c_void_p, c_int, c_int, c_int, c_int, c_int, C.POINTER(Settings), C.POINTER(C.c_void_p)]
     L.qpg_batch_set_problem.argtypes = [C.c_void_p, c_int, pi, pi, pf, pi, pi, pf, pf, c_float, pf, pf]
     L.qpg_batch_set_problem_sized.argtypes = [C.c_void_p, c_int, c_int, c_int, pi, pi, pf, pi, pi, pf, pf, c_float, pf, pf]
+    pp = C.POINTER(C.c_void_p)
+    L.qpg_batch_set_problems.argtypes = [C.c_void_p, c_int, c_int, pi, pi, pp, pp, pp, pp, pp, pp, pp, pf, pp, pp]
     for f in ("qpg_batch_setup", "qpg_batch_solve", "qpg_batch_sync", "qpg_batch_begin_solve", "qpg_batch_warm_start_last"):
         getattr(L, f).argtypes = [C.c_void_p]
     L.qpg_batch_warm_start.argtypes = [C.c_void_p, pf, pf]
@@ -138,7 +140,7 @@ SYMBOLS = [
     "qpg_ldlupdate_sigma_changed", "qpg_ldlsolveLD_neg_dphi", "qpg_compute_residuals", "qpg_set_active_constraints",
     "qpg_exact_linesearch", "qpg_batch_ldlsolve_all", "qpg_batch_sweep_probe", "qpg_kkt_form", "qpg_kkt_factorize",
     "qpg_kkt_update_entering_constraints", "qpg_kkt_update_leaving_constraints", "qpg_kkt_solve", "qpg_ldlchol_matrix", "qpg_sparse_matvec",
-    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_ctx_hbm_read_gbs", "qpg_host_alloc", "qpg_host_free", "qpg_batch_set_problem_sized",
+    "qpg_batch_begin_solve", "qpg_batch_get_info_all", "qpg_batch_get_stats_all", "qpg_ctx_hbm_copy_gbs", "qpg_ctx_hbm_read_gbs", "qpg_host_alloc", "qpg_host_free", "qpg_batch_set_problem_sized", "qpg_batch_set_problems",
 ]
 
 

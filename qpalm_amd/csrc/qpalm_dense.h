@@ -1112,6 +1112,13 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
 #ifndef QP_RECUR_DPP
 #define QP_RECUR_DPP 1
 #endif
+#ifndef QP_PANEL_A_DPP
+#define QP_PANEL_A_DPP 1 /* the same hand-over when the panel wave applies the finished table s-1 to the rows of block s (see there) */
+#endif
+#ifndef QP_OWNER_DPP32
+#define QP_OWNER_DPP32 1 /* ... and in the owners' loop of the 32-rank form (one row per lane: a broadcast LDS read per rank and column serves two FMAs
+                            only, the LDS pipe of the CU is the bound; two lane-indexed reads per column + DPP broadcasts instead) */
+#endif
 
 /* ---------------------------------------------------------------------------------------------
  * K = 32 (round 4): TWICE the ranks per pass over the panel = half the panel traffic per rank.  Two things make that fit:
@@ -1230,6 +1237,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
     auto apply_table = [&](const int tb, const int Jc, const bool ok) QP_ALWAYS_INLINE {
       constexpr int QD = (K > 16) ? 2 * QP_TQD : QP_TQD; /* one row per thread, 8-byte accesses: twice the columns in flight */
       static_assert(NB % QD == 0, "queue depth divides the block");
+      constexpr bool ODPP = QP_OWNER_DPP32 && (K > 16); /* pairs by lane-indexed reads + DPP broadcast instead of K broadcast reads per column */
+      const qp_pair QP_LDS_AS *tabO = (const qp_pair QP_LDS_AS *)QP_LDS_VBASE(&QP_CWG(U, tb, 0)[lane & 15][0]);
       const int i0 = R0 + tid * RPT;
       qp_gdouble *rowp = ok ? (L + (size_t)Jc * ld + i0) : (dummy + tid * RPT);
       const size_t cstride = ok ? (size_t)ld : 0;
@@ -1245,6 +1254,20 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
 #pragma unroll
           for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
+          if constexpr (ODPP) {
+            qp_pair cf[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) cf[g] = tabO[c1 * K + 16 * g];
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) {
+              qp_apply_ranks_dpp<K, 0, 0, 8>(cf[0].x, cf[0].y, w[rr], l[rr]);
+              if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16>(cf[0].x, cf[0].y, w[rr], l[rr]);
+              if constexpr (G > 1) {
+                if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8>(cf[G - 1].x, cf[G - 1].y, w[rr], l[rr]);
+                if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16>(cf[G - 1].x, cf[G - 1].y, w[rr], l[rr]);
+              }
+            }
+          } else {
 #pragma unroll
           for (int rb = 0; rb < K; rb += 4) {
             if (rb >= kk) break; /* ranks >= kk: exact no-ops, skipped */
@@ -1264,6 +1287,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               }
             }
             QP_SCHED_BARRIER();
+          }
           }
           qp_store_rows_nt<RPT>(rowp + (size_t)c1 * cstride, l);
           if (fuse) { /* column Jc + c1 is final for these rows: its term of the forward substitution */
@@ -1321,7 +1345,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       __syncthreads();
       for (int b = 0; b < nrb; b++) {
         if (b + 1 < nrb) tab_load(b + 1);
-        if (ok) apply_table(b & 1, J0 + b * NB, true);
+        if (__ballot(ok ? 1 : 0) != 0ull) apply_table(b & 1, J0 + b * NB, ok); /* whole wavefronts: the DPP broadcasts need every lane of a row */
         if (b + 1 < nrb) tab_store(b + 1);
         __syncthreads();
       }
@@ -1368,7 +1392,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         bool any = false;
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) { const int i = R0 + tid * RPT + rr; any = any || (i >= Jn && i < R1); }
-        if (s > 0 && any) {
+        constexpr bool WAVES = QP_OWNER_DPP32 && (K > 16); /* DPP form: whole wavefronts take part (idle lanes work on their dummy cell) */
+        if (s > 0 && (WAVES ? (__ballot(any ? 1 : 0) != 0ull) : any)) {
           const int i0 = R0 + tid * RPT;
           apply_table(prv, Jp, i0 >= Jn && i0 < rlim);
         }
@@ -1419,12 +1444,31 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * (Tried in round 2 and measured slower on MI355X in the full kernel, although faster in isolation: register
            * rotation of the (-w_j, -gamma) pairs, and two columns at a time skewed by one rank.  The panel wave is bound by
            * the number of instructions it issues, ~6.5 clk each, not by the FMA dependences.) */
+          /* QP_PANEL_A_DPP: the (-w_j, -gamma) pairs of a column are fetched with ONE lane-indexed 16-byte LDS read per rank group (lane
+           * & 15 = rank: every 16-lane row holds the group's pairs), QD columns ahead like the entries of L, and rank r's pair reaches
+           * the row lanes by DPP row broadcast as in the recurrence: K broadcast reads and their waits per column leave the chain. */
+          const qp_pair QP_LDS_AS *tabA = (const qp_pair QP_LDS_AS *)QP_LDS_VBASE(&QP_CWG(U, prv, 0)[lane & 15][0]);
+          qp_pair cfq[QP_PANEL_A_DPP ? QD : 1][G];
+          if (QP_PANEL_A_DPP) {
+#pragma unroll
+            for (int cc = 0; cc < QD; cc++)
+#pragma unroll
+              for (int g = 0; g < G; g++) cfq[cc][g] = tabA[cc * K + 16 * g];
+          }
           auto group = [&](const int c0) QP_ALWAYS_INLINE {
 #pragma unroll
             for (int u = 0; u < QD; u++) {
               const int c1 = c0 + u;
               double l = q[u];
               const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
+              if (QP_PANEL_A_DPP) {
+                qp_apply_ranks_dpp<K, 0, 0, 8>(cfq[u][0].x, cfq[u][0].y, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
+                if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16>(cfq[u][0].x, cfq[u][0].y, wrow, l);
+                if constexpr (G > 1) {
+                  if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8>(cfq[u][G - 1].x, cfq[u][G - 1].y, wrow, l);
+                  if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16>(cfq[u][G - 1].x, cfq[u][G - 1].y, wrow, l);
+                }
+              } else {
 #pragma unroll
               for (int rb = 0; rb < K; rb += 8) {
                 if (rb >= kk) break; /* ranks >= kk are exact no-ops (w = 0, gamma = 0): skipped, wave-uniform */
@@ -1440,10 +1484,15 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 }
                 if (K > 16) QP_SCHED_BARRIER(); /* 32 ranks: one group of eight pairs in registers at a time */
               }
+              }
               rowp[(size_t)c1 * cstride] = l;
               if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
               QP_SCHED_BARRIER();
               q[u] = PSQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
+              if (QP_PANEL_A_DPP) {
+#pragma unroll
+                for (int g = 0; g < G; g++) cfq[u][g] = tabA[cpre * K + 16 * g];
+              }
               QP_SCHED_BARRIER();
             }
           };

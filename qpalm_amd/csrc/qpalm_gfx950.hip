@@ -92,6 +92,26 @@ template <class K> static void rt_allow_lds(K kernel, size_t shmem) { /* once pe
 #define RT_MEMCPY_D2H(dst, src, bytes) rt_check(hipMemcpy((void *)(dst), (const void *)(src), (bytes), hipMemcpyDeviceToHost), "hipMemcpy D2H")
 #define RT_MEMCPY2D_H2D(dst, dpitch, src, spitch, width, height) rt_check(hipMemcpy2D((void *)(dst), (dpitch), (const void *)(src), (spitch), (width), (height), hipMemcpyHostToDevice), "hipMemcpy2D H2D")
 #define RT_MEMSET(dst, val, bytes) rt_check(hipMemset((void *)(dst), (val), (bytes)), "hipMemset")
+/* asynchronous uploads from page-locked staging on a copy stream of their own; RT_COPY_MARK(k) records "everything issued so far" for
+ * staging buffer k, RT_COPY_WAIT(k) waits for it on the host */
+static hipStream_t g_rt_copy_stream = 0;
+static hipEvent_t g_rt_copy_event[2] = {0, 0};
+static int g_rt_copy_marked[2] = {0, 0};
+static int rt_copy_async(void *dst, const void *src, size_t bytes) {
+  if (!g_rt_copy_stream && rt_check(hipStreamCreateWithFlags(&g_rt_copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return 1;
+  return rt_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_rt_copy_stream), "hipMemcpyAsync H2D");
+}
+static void rt_copy_mark(int k) {
+  if (!g_rt_copy_event[k] && hipEventCreateWithFlags(&g_rt_copy_event[k], hipEventDisableTiming) != hipSuccess) { g_rt_copy_event[k] = 0; (void)hipStreamSynchronize(g_rt_copy_stream); return; }
+  (void)hipEventRecord(g_rt_copy_event[k], g_rt_copy_stream);
+  g_rt_copy_marked[k] = 1;
+}
+static void rt_copy_wait(int k) {
+  if (g_rt_copy_marked[k]) { rt_check(hipEventSynchronize(g_rt_copy_event[k]), "hipEventSynchronize"); g_rt_copy_marked[k] = 0; }
+}
+#define RT_MEMCPY_H2D_ASYNC(dst, src, bytes, k) rt_copy_async((void *)(dst), (const void *)(src), (bytes))
+#define RT_COPY_MARK(k) rt_copy_mark(k)
+#define RT_COPY_WAIT(k) rt_copy_wait(k)
 #define RT_SYNC() rt_sync()
 #define RT_STICKY() (g_rt_sticky)
 #define RT_STICKY_CLEAR() (g_rt_sticky = 0)

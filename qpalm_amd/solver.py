@@ -100,11 +100,20 @@ class QpalmBatch:
         t0 = time.perf_counter()
         self._check(self.L.qpg_batch_create(ctx.h, self.B, self.n, self.m, nnzA, nnzQ, C.byref(self.settings), C.byref(h)))
         self.h = h
+        # every member in ONE call (qpg_batch_set_problems: arrays of pointers, the conversion to the device layout runs on host threads)
+        B = self.B
+        keep = []   # contiguous int64 / float64 views stay alive until the call returns
+        cols = [(C.c_void_p * B)() for _ in range(9)]
         for b, p in enumerate(problems):
-            Qp, Qi, Qx, Ap, Ai, Ax = i64(p.Qp), i64(p.Qi), f64(p.Qx), i64(p.Ap), i64(p.Ai), f64(p.Ax)
-            q, bmin, bmax = f64(p.q), f64(p.bmin), f64(p.bmax)
-            self._check(self.L.qpg_batch_set_problem_sized(self.h, b, int(p.n), int(p.m), iptr(Qp), iptr(Qi), fptr(Qx), iptr(Ap), iptr(Ai),
-                                                           fptr(Ax), fptr(q), float(getattr(p, "c", 0.0)), fptr(bmin), fptr(bmax)))
+            arrs = (i64(p.Qp), i64(p.Qi), f64(p.Qx), i64(p.Ap), i64(p.Ai), f64(p.Ax), f64(p.q), f64(p.bmin), f64(p.bmax))
+            keep.append(arrs)
+            for k, a in enumerate(arrs):
+                cols[k][b] = a.ctypes.data
+        ns, ms = i64([int(p.n) for p in problems]), i64([int(p.m) for p in problems])
+        cs = f64([float(getattr(p, "c", 0.0)) for p in problems])
+        self._check(self.L.qpg_batch_set_problems(self.h, 0, B, iptr(ns), iptr(ms), cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], cols[6],
+                                                   fptr(cs), cols[7], cols[8]))
+        del keep
         t1 = time.perf_counter()
         self._check(self.L.qpg_batch_setup(self.h))
         # what qpalm_setup does (src/qpalm.c:73-319), split as this engine does it: host-side copies / format conversion of every

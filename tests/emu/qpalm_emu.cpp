@@ -24,6 +24,9 @@ static int rt_malloc(void **pp, size_t bytes) { *pp = calloc(bytes ? bytes : 1, 
 #define RT_MEMCPY_D2H(dst, src, bytes) memcpy((void *)(dst), (const void *)(src), (bytes))
 #define RT_MEMCPY2D_H2D(dst, dpitch, src, spitch, width, height) do { for (size_t r_ = 0; r_ < (size_t)(height); r_++) memcpy((char *)(dst) + r_ * (dpitch), (const char *)(src) + r_ * (spitch), (width)); } while (0)
 #define RT_MEMSET(dst, val, bytes) memset((void *)(dst), (val), (bytes))
+#define RT_MEMCPY_H2D_ASYNC(dst, src, bytes, k) memcpy((void *)(dst), (const void *)(src), (bytes))
+#define RT_COPY_MARK(k) do { } while (0)
+#define RT_COPY_WAIT(k) do { } while (0)
 #define RT_SYNC() 0
 #define RT_STICKY() 0
 #define RT_STICKY_CLEAR() do { } while (0)

@@ -99,7 +99,7 @@ def test_sweep32_factor_bit_identical_to_sweep16_and_matches_oracle(ctx, shape):
                 bt.close()
             o.cleanup()
     finally:
-        ctx.set_option("sweep_ranks", 32)
+        ctx.set_option("sweep_ranks", 16)
 
 
 def test_sweep32_whole_solve_bit_identical(ctx):
@@ -118,7 +118,7 @@ def test_sweep32_whole_solve_bit_identical(ctx):
                        [int(s.n_rank1) for s in bt.stats_all()], [int(s.sweep_entries) for s in bt.stats_all()])
             bt.close()
     finally:
-        ctx.set_option("sweep_ranks", 32)
+        ctx.set_option("sweep_ranks", 16)
     (x32, y32), info32, sw32, r32, e32 = res[32]
     (x16, y16), info16, sw16, r16, e16 = res[16]
     assert info32 == info16 and r32 == r16

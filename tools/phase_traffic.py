@@ -41,7 +41,7 @@ def run(args):
     ms0 = bt.sweep_probe(0, 16)
     st = bt.stats_all()
     out["factor"] = {"ms": ms0, "reread_entries": float(np.mean([s.factor_reread_entries for s in st]))}
-    for ranks in (16, 8):
+    for ranks in (16, 8, 64):   # 64: four sweeps per call of the update (per-call costs -- callee-saved registers to scratch -- spread over four)
         ms = bt.sweep_probe(args.reps, ranks)
         st = bt.stats_all()
         out["sweep%d" % ranks] = {"ms": ms, "sweeps": float(np.mean([s.n_sweeps for s in st])),
@@ -89,15 +89,18 @@ def summarise(d):
         need_factor = (nnzL * 8 + info["factor"]["reread_entries"] * 8 + (info["nnzA"] + info["nnzQ"]) * 12) / 1e6
         res["factor"] = {"read": 2 * fs[0] * KB, "write": ws[0] * KB, "needed_write": nnzL * 8 / 1e6,
                          "needed_incl_documented_rereads": need_factor, "compulsory": (nnzL * 8 + (info["nnzA"] + info["nnzQ"]) * 12) / 1e6}
-        for j, key in ((1, "sweep16"), (2, "sweep8")):
-            ent = info[key]["entries"] / max(info[key]["sweeps"], 1)
-            res[key] = {"read": 2 * (fs[j] - fs[0]) * KB / R2, "write": (ws[j] - ws[0]) * KB / R2, "needed_read": ent * 8 / 1e6, "needed_write": ent * 8 / 1e6,
-                        "us_per_sweep": 1e3 * (info[key]["ms"] - info["factor"]["ms"]) / R2}
+        for j, key in ((1, "sweep16"), (2, "sweep8"), (3, "sweep64")):
+            if key not in info or len(fs) <= j:
+                continue
+            nsw = max(info[key]["sweeps"], 1)    # sweeps of the probe launch (2 R calls x ceil(ranks / 16))
+            ent = info[key]["entries"] / nsw
+            res[key] = {"read": 2 * (fs[j] - fs[0]) * KB / nsw, "write": (ws[j] - ws[0]) * KB / nsw, "needed_read": ent * 8 / 1e6, "needed_write": ent * 8 / 1e6,
+                        "us_per_sweep": 1e3 * (info[key]["ms"] - info["factor"]["ms"]) / nsw, "sweeps_per_call": nsw / R2}
     if fl and wl:
         S = info["solve_reps"]
         res["solve"] = {"read": 2 * fl[0] * KB / S, "write": wl[0] * KB / S, "needed_read": (2 * nnzL * 8 + 16 * n) / 1e6, "needed_write": 8 * n / 1e6,
                         "ms_per_solve": info["solve"]["ms_per_rep"]}
-    for k in ("factor", "sweep16", "sweep8", "solve"):
+    for k in ("factor", "sweep16", "sweep8", "sweep64", "solve"):
         if k in res:
             r = res[k]
             need = r.get("needed_incl_documented_rereads", r.get("needed_read", 0) + r.get("needed_write", 0))
