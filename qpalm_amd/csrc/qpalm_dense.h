@@ -1112,6 +1112,9 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
 #ifndef QP_RECUR_DPP
 #define QP_RECUR_DPP 1
 #endif
+#ifndef QP_SQ_WB
+#define QP_SQ_WB 0 /* 1 (measured in round 4: no gain, 5186-5191 against 5206-5216 QP/s same box): the panel wave writes the entries of the staged square back into LDS, not to HBM (see its loop) */
+#endif
 #ifndef QP_PANEL_A_DPP
 #define QP_PANEL_A_DPP 1 /* the same hand-over when the panel wave applies the finished table s-1 to the rows of block s (see there) */
 #endif
@@ -1485,7 +1488,12 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                 if (K > 16) QP_SCHED_BARRIER(); /* 32 ranks: one group of eight pairs in registers at a time */
               }
               }
-              rowp[(size_t)c1 * cstride] = l;
+              /* QP_SQ_WB: the final entry goes back into the staged square (the owners write the square to HBM while they stage the next
+               * one), so that the serial chain issues no global-memory instruction at all: a global store of the panel wave queues up
+               * behind the owners' streaming loads and stores in the CU's memory pipeline (round 3's knock-outs: the owners' HBM traffic,
+               * not their FMAs or LDS reads, slowed this loop by a third). */
+              if (PSQ && QP_SQ_WB) { if (lane < NB) U.Lsq[cur][c1][lrow] = l; }
+              else rowp[(size_t)c1 * cstride] = l;
               if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
               QP_SCHED_BARRIER();
               q[u] = PSQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
@@ -1654,6 +1662,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               if (s > 0) L[(size_t)(Jp + c1) * ld + (Jp + c)] = U.Ld[prv][c][c1];
               if (c < jbn) U.Ld[prv][c][c1] = L[(size_t)(Jn + c1) * ld + (Jn + c)];
             }
+            /* the square of the LAST phase (rows of block s-1, columns of block s-2: block s-1 is a full block) as the panel wave left it: back to HBM */
+            if (QP_SQ_WB && s >= 2) L[(size_t)(Jp - NB + c1) * ld + (Jp + c)] = U.Lsq[prv][c1][c];
             /* next phase: the panel wave applies table s to the rows of block s+1 */
             if (jbn > 0) U.Lsq[prv][c1][c] = (c < jbn) ? L[(size_t)(J + c1) * ld + (Jn + c)] : 0.0;
           }
@@ -1674,6 +1684,8 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       for (int e = tid; e < NB * NB; e += QP_T) {
         const int c1 = e / NB, c = e % NB;
         if (c > c1 && c < jbl) L[(size_t)(Jl + c1) * ld + (Jl + c)] = U.Ld[sl & 1][c][c1];
+        /* ... and the square the panel wave updated in the last phase (rows of the last block, columns of the one before) */
+        if (QP_SQ_WB && sl >= 1 && c < jbl) L[(size_t)(Jl - NB + c1) * ld + (Jl + c)] = U.Lsq[sl & 1][c1][c];
       }
     }
     if (MP && !last_pass) export_table((nblk - 1) & 1, Js + (nblk - 1) * NB, tid, QP_T); /* the pass's last table */
