@@ -151,8 +151,7 @@ int  qpg_batch_set_problem_sized(qpg_batch *bt, qpg_int idx, qpg_int n, qpg_int 
                                  const qpg_float *q, qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
 /* qpg_batch_set_problem_sized for members first .. first + count - 1 in ONE call (entry k of every array = member first + k; n / m
  * NULL: every member has the batch's dimensions; c NULL: zero constants): the per-QP host work of qpalm_setup -- deep copies,
- * sorted CSC, the A' pattern (src/qpalm.c:128-144, iteration.c:81) -- runs on host threads (QPALM_HOST_THREADS, default: all,
- * at most 64).  No reference counterpart (the reference sets up one QP per call). */
+ * sorted CSC, the A' pattern (src/qpalm.c:128-144, iteration.c:81) -- runs on host threads (QPALM_HOST_THREADS; default: at most 12).  No reference counterpart (the reference sets up one QP per call). */
 int  qpg_batch_set_problems(qpg_batch *bt, qpg_int first, qpg_int count, const qpg_int *n, const qpg_int *m,
                             const qpg_int *const *Qp, const qpg_int *const *Qi, const qpg_float *const *Qx,
                             const qpg_int *const *Ap, const qpg_int *const *Ai, const qpg_float *const *Ax,

@@ -9,7 +9,7 @@ for rep in 1 2; do
   for v in "$@"; do
     name=${v%%:*}; args=${v#*:}; [ "$args" = "$v" ] && args=""
     lib=$REPO/qpalm_amd/lib/libqpalm_gfx950_$name.so; [ "$name" = "cur" ] && lib=$REPO/qpalm_amd/lib/libqpalm_gfx950.so
-    timeout 900 python bench.py --no-cpu --no-mpc --lib $lib $args > gpurun_out/$tag/bench_${k}_$rep.json 2>> gpurun_out/$tag/bench.err
+    timeout 400 python bench.py --no-cpu --no-mpc --lib $lib $args > gpurun_out/$tag/bench_${k}_$rep.json 2>> gpurun_out/$tag/bench.err
     k=$((k+1))
   done
 done
