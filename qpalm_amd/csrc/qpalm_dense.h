@@ -1116,10 +1116,8 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
 #define QP_SQ_WB 0 /* 1 (measured in round 4: no gain, 5186-5191 against 5206-5216 QP/s same box): the panel wave writes the entries of the staged square back into LDS, not to HBM (see its loop) */
 #endif
 #ifndef QP_PANEL_A_DPP
-#define QP_PANEL_A_DPP 1 /* the same hand-over when the panel wave applies the finished table s-1 to the rows of block s (see there) */
-#endif
-#ifndef QP_TAB_SCALAR
-#define QP_TAB_SCALAR 1 /* 32-rank form: the owners take the table pairs from the export area with scalar loads, as SGPR operands (qp_sload_tab4) */
+#define QP_PANEL_A_DPP (K <= 16) /* the same hand-over when the panel wave applies the finished table s-1 to the rows of block s (see there);
+                                    measured: K = 16 panel wave 57.0 -> 55.0 ms per QP; K = 32: slower (4.43 vs 4.65 k QP/s), so not there */
 #endif
 #ifndef QP_OWNER_DPP32
 #define QP_OWNER_DPP32 1 /* ... and in the owners' loop of the 32-rank form (one row per lane: a broadcast LDS read per rank and column serves two FMAs
@@ -1202,7 +1200,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
     } else jmin = (pre_jmin < n) ? pre_jmin : n - 1;
     if (fuse) jmin = 0;
     jmin = QP_UNIFORM(block_imin(S, jmin)); /* same value in every lane: keep the block loops scalar */
-    if (MP && QP_TAB_SCALAR) QP_SCACHE_INV(); /* lines of the export area from an earlier sweep */
     /* lane r of every 16-lane row of the panel wave carries alpha_r and 1/alpha_r of rank 16 g + r (QP_RECUR_DPP; else lane r, G = 1);
      * they run on through the passes */
     double alpha[G], ialpha[G], sg[G];
@@ -1241,40 +1238,17 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
      * the column QD ahead is prefetched into a register queue; the (-w_j, -gamma) pairs come as 16-byte LDS broadcasts, four
      * ranks at a time.  Register budget <= 128 VGPRs so that two workgroups share a CU.  The RPT adjacent rows of a thread are
      * one access group: 16-byte loads/stores (RPT even), one address and one liveness per thread. */
-    auto apply_table = [&](const int tb, const int Jc, const bool ok, const bool ys_lds, const bool more_after) QP_ALWAYS_INLINE {
+    auto apply_table = [&](const int tb, const int Jc, const bool ok) QP_ALWAYS_INLINE {
       constexpr int QD = (K > 16) ? 2 * QP_TQD : QP_TQD; /* one row per thread, 8-byte accesses: twice the columns in flight */
       static_assert(NB % QD == 0, "queue depth divides the block");
-      constexpr bool OSC = MP && QP_TAB_SCALAR;            /* pairs from the export area by scalar loads, as SGPR operands (qp_sload_tab4) */
-      constexpr bool ODPP = !OSC && QP_OWNER_DPP32 && (K > 16); /* pairs by lane-indexed reads + DPP broadcast instead of K broadcast reads per column */
+      constexpr bool ODPP = QP_OWNER_DPP32 && (K > 16); /* pairs by lane-indexed reads + DPP broadcast instead of K broadcast reads per column */
       const qp_pair QP_LDS_AS *tabO = (const qp_pair QP_LDS_AS *)QP_LDS_VBASE(&QP_CWG(U, tb, 0)[lane & 15][0]);
       const int i0 = R0 + tid * RPT;
       qp_gdouble *rowp = ok ? (L + (size_t)Jc * ld + i0) : (dummy + tid * RPT);
       const size_t cstride = ok ? (size_t)ld : 0;
       double q[QD][RPT];
-      double yq[QD]; /* fused solve outside the look-ahead phases: y of the columns travels with the entries */
 #pragma unroll
-      for (int cc = 0; cc < QD; cc++) { qp_load_rows_nt<RPT>(rowp + (size_t)cc * cstride, q[cc]); yq[cc] = (fuse && !ys_lds) ? fs[Jc + cc] : 0.0; }
-      /* scalar form: chunks of four ranks (64 bytes) alternate between two register sets; a chunk is requested one FMA block ahead.  Every
-       * column takes an even number of chunks (the odd one out holds ranks >= kk of a group that was written: zero pairs, exact no-ops) */
-      const int kk2 = (kk + 7) & ~7;
-#ifdef QPALM_EMU
-      const double *tabS = (const double *)Tab;
-#else
-      const double *tabS; /* the base back in an SGPR pair (function arguments arrive in VGPRs) */
-      { const unsigned long long a = (unsigned long long)(size_t)(const double *)Tab;
-        tabS = (const double *)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a)); }
-#endif
-      qp_tab4 tA, tB;
-      if (OSC) tA = qp_sload_tab4(tabS, Jc * (K * 16));
-      auto fma4 = [&](const qp_tab4 &t, const int rbase, double (&l)[RPT]) QP_ALWAYS_INLINE {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) {
-            w[rr][(rbase + r) & (K - 1)] = QP_FMA(t.get(2 * r), l[rr], w[rr][(rbase + r) & (K - 1)]);
-            l[rr] = QP_FMA(t.get(2 * r + 1), w[rr][(rbase + r) & (K - 1)], l[rr]);
-          }
-      };
+      for (int cc = 0; cc < QD; cc++) qp_load_rows_nt<RPT>(rowp + (size_t)cc * cstride, q[cc]);
       auto group = [&](const int c0) QP_ALWAYS_INLINE {
 #pragma unroll
         for (int u = 0; u < QD; u++) { /* queue slot u = fixed registers (see the panel wave's loop) */
@@ -1284,21 +1258,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
 #pragma unroll
           for (int rr = 0; rr < RPT; rr++) l[rr] = q[u][rr];
-          if constexpr (OSC) {
-            const int tboff = (Jc + c1) * (K * 16);
-            /* the first chunk of the next column (of the next block of this call chain, if one follows: the tables are contiguous) */
-            const int tbnext = (c1 + 1 < NB || more_after) ? tboff + K * 16 : tboff;
-#pragma unroll
-            for (int ch = 0; ch < K / 4; ch += 2) {
-              if (4 * ch >= kk2) break; /* wave-uniform */
-              QP_SWAIT_FOR(tA);
-              tB = qp_sload_tab4(tabS, tboff + (ch + 1) * 64);
-              fma4(tA, 4 * ch, l);
-              QP_SWAIT_FOR(tB);
-              tA = qp_sload_tab4(tabS, (4 * (ch + 2) < kk2) ? tboff + (ch + 2) * 64 : tbnext);
-              fma4(tB, 4 * (ch + 1), l);
-            }
-          } else
           if constexpr (ODPP) {
             qp_pair cf[G];
 #pragma unroll
@@ -1336,13 +1295,12 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           }
           qp_store_rows_nt<RPT>(rowp + (size_t)c1 * cstride, l);
           if (fuse) { /* column Jc + c1 is final for these rows: its term of the forward substitution */
-            const double yv = ys_lds ? U.ys[tb][c1] : yq[u];
+            const double yv = U.ys[tb][c1];
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) acc[rr] = QP_FMA(-l[rr], yv, acc[rr]);
           }
           QP_SCHED_BARRIER();
           qp_load_rows_nt<RPT>(rowp + (size_t)cpre * cstride, q[u]); /* refill after the slot is free */
-          if (fuse && !ys_lds) yq[u] = fs[Jc + cpre];
           QP_SCHED_BARRIER();
         }
       };
@@ -1358,17 +1316,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         Tab[((size_t)Jc * K + e) * 2] = v.x; Tab[((size_t)Jc * K + e) * 2 + 1] = v.y;
       }
     };
-    if constexpr (MP && QP_TAB_SCALAR) {
-      if (R0 > J0) {
-        /* ===== rectangle: the tables of the earlier pass's columns [J0, R0) on this pass's rows, every wavefront for itself (the pairs
-         * come straight from the export area as SGPR operands: no staging, no barrier, no serial chain) ============================ */
-        const int nrb = (R0 - J0) / NB;
-        const int i0 = R0 + tid * RPT;
-        const bool ok = (i0 < rlim);
-        if (__ballot(ok ? 1 : 0) != 0ull)
-          for (int b = 0; b < nrb; b++) apply_table(0, J0 + b * NB, ok, false, b + 1 < nrb);
-      }
-    } else
     if constexpr (MP) if (R0 > J0) {
       /* ===== rectangle: the tables of the earlier passes' columns [J0, R0) on this pass's rows, every wavefront, no serial chain.
        * Block b + 1 of the export area travels through registers into U.cwg[(b + 1) & 1] (+ y of its columns into U.ys) while
@@ -1402,7 +1349,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       __syncthreads();
       for (int b = 0; b < nrb; b++) {
         if (b + 1 < nrb) tab_load(b + 1);
-        if (__ballot(ok ? 1 : 0) != 0ull) apply_table(b & 1, J0 + b * NB, ok, true, false); /* whole wavefronts: the DPP broadcasts need every lane of a row */
+        if (__ballot(ok ? 1 : 0) != 0ull) apply_table(b & 1, J0 + b * NB, ok); /* whole wavefronts: the DPP broadcasts need every lane of a row */
         if (b + 1 < nrb) tab_store(b + 1);
         __syncthreads();
       }
@@ -1449,10 +1396,10 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         bool any = false;
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) { const int i = R0 + tid * RPT + rr; any = any || (i >= Jn && i < R1); }
-        constexpr bool WAVES = MP && (QP_TAB_SCALAR || QP_OWNER_DPP32); /* DPP / scalar forms: whole wavefronts take part (idle lanes work on their dummy cell) */
+        constexpr bool WAVES = MP && QP_OWNER_DPP32; /* DPP form: whole wavefronts take part (idle lanes work on their dummy cell) */
         if (s > 0 && (WAVES ? (__ballot(any ? 1 : 0) != 0ull) : any)) {
           const int i0 = R0 + tid * RPT;
-          apply_table(prv, Jp, i0 >= Jn && i0 < rlim, true, false);
+          apply_table(prv, Jp, i0 >= Jn && i0 < rlim);
         }
         /* rows of block s+1 to the hand-over buffer of the next phase */
 #pragma unroll
@@ -1612,10 +1559,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
             const double gam = -sg[g] * wv * ialpha[g] * rdn;
             if (ln < KG) { QP_CWG(U, cur, c1)[16 * g + ln][0] = -wv; QP_CWG(U, cur, c1)[16 * g + ln][1] = -gam; } /* stored negated: plain FMAs below */
-            if (MP && QP_TAB_SCALAR && ln < KG) { /* ... and to the export area: the owners' scalar loads and the later pass read it there */
-              qp_gdouble *tq = Tab + ((size_t)(J + c1) * K + 16 * g + ln) * 2;
-              tq[0] = -wv; tq[1] = -gam;
-            }
             /* a rank whose vector is zero in this column leaves its alpha alone: d_new / d_prev is exactly 1 there, d * rcp(d) is not.
              * (Columns above a rank's first nonzero are then exact no-ops: the result does not depend on where a sweep starts or on
              * how the ranks are grouped into sweeps.) */
@@ -1705,7 +1648,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           for (int r = 0; r < K; r++) w[rr][r] = own_live0 ? U.stash[rr][r][lane] : 0.0;
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live0 ? U.stash_acc[rr][lane] : 0.0;
-        if (MP && QP_TAB_SCALAR) QP_VMEM_DRAIN(); /* the table's stores are in L2 before the barrier that lets the scalar loads at them */
         QP_SETPRIO(0);
         if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
         if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
@@ -1736,7 +1678,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           }
         }
         if (t0 < jbn) U.dd[prv][t0] = Dg[Jn + t0];
-        if (MP && !QP_TAB_SCALAR && !last_pass && s > 0) export_table(prv, Jp, t0, nt); /* table s-1 is complete: the later passes' rows need it */
+        if (MP && !last_pass && s > 0) export_table(prv, Jp, t0, nt); /* table s-1 is complete: the later passes' rows need it */
       }
       __syncthreads();
       if (QP_PANEL_TIMING == 1 && tid == 0) tdbg[11] += QP_CLOCK() - tpe;
@@ -1750,7 +1692,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
         if (QP_SQ_WB && sl >= 1 && c < jbl) L[(size_t)(Jl - NB + c1) * ld + (Jl + c)] = U.Lsq[sl & 1][c1][c];
       }
     }
-    if (MP && !QP_TAB_SCALAR && !last_pass) export_table((nblk - 1) & 1, Js + (nblk - 1) * NB, tid, QP_T); /* the pass's last table */
+    if (MP && !last_pass) export_table((nblk - 1) & 1, Js + (nblk - 1) * NB, tid, QP_T); /* the pass's last table */
     } /* passes */
     if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[7] += tq1 - tq0; tq0 = tq1; }
   }

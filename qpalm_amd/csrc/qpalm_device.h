@@ -98,12 +98,6 @@ typedef emu_double4 qp_double4;
 #define QP_FRESH_LANE(lane) (lane)
 #define QP_CALL_BLOCK() 1
 #define QP_ALWAYS_INLINE
-/* four (-w_j, -gamma) pairs of an exported table (64 bytes at a wave-uniform address), see the hardware form below */
-struct qp_tab4 { double v[8]; __device__ double get(int k) const { return v[k]; } };
-static inline qp_tab4 qp_sload_tab4(const double *base, int byte_off) { qp_tab4 t; const double *p = (const double *)((const char *)base + byte_off); for (int k = 0; k < 8; k++) t.v[k] = p[k]; return t; }
-#define QP_SWAIT_FOR(t) do { } while (0)
-#define QP_SCACHE_INV() do { } while (0)
-#define QP_VMEM_DRAIN() do { } while (0)
 /* emulation: one "CU", wavefront w sits on "SIMD" w & 3 (exercises the panel-wave rotation) */
 #define QP_HW_CU_KEY() 0
 #define QP_HW_SIMD() ((int)(threadIdx.x >> 6) & 3)
@@ -150,31 +144,6 @@ static __device__ __forceinline__ int qp_opaque_true_() {
 }
 #define QP_CALL_BLOCK() qp_opaque_true_()
 #define QP_ALWAYS_INLINE __attribute__((always_inline))
-/* Wave-uniform coefficients belong in SGPRs: four (-w_j, -gamma) pairs of an exported table (64 bytes at a wave-uniform address in
- * HBM / L2) come in with ONE scalar load through the scalar data cache and are used as SGPR operands of the FMAs -- no LDS read, no
- * VALU instruction, no VGPR per coefficient.  The scalar cache is not coherent with vector stores: the producer drains its stores
- * (QP_VMEM_DRAIN before the workgroup barrier: they are in L2 then), the consumers drop stale lines of an earlier sweep once per
- * sweep (QP_SCACHE_INV); within a sweep every address is written once, before the barrier that precedes its first read.
- * Scalar loads return out of order: QP_SWAIT_FOR (lgkmcnt(0), tied to the loaded registers) before a loaded value is used. */
-#ifndef QP_SLOAD_GLC
-#define QP_SLOAD_GLC 0
-#endif
-typedef int qp_i16v __attribute__((ext_vector_type(16)));
-struct qp_tab4 { qp_i16v r; __device__ __forceinline__ double get(int k) const { return __hiloint2double(r[2 * k + 1], r[2 * k]); } };
-static __device__ __forceinline__ qp_tab4 qp_sload_tab4(const double *base, int byte_off) {
-  qp_tab4 t;
-#if QP_SLOAD_GLC
-  asm volatile("s_load_dwordx16 %0, %1, %2 glc" : "=s"(t.r) : "s"(base), "s"(byte_off) : "memory"); /* experiment: past the scalar cache */
-#else
-  asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(t.r) : "s"(base), "s"(byte_off) : "memory");
-#endif
-  return t;
-}
-/* the wait names the registers it waits for: their uses are then ordered behind it by a data dependence (a bare s_waitcnt is only a memory
- * barrier to the compiler, which is free to schedule the FMAs that read the loaded SGPRs ahead of it) */
-#define QP_SWAIT_FOR(t) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"((t).r) : : "memory")
-#define QP_SCACHE_INV() do { __builtin_amdgcn_s_dcache_inv(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
-#define QP_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 /* where this wavefront runs: HW_REG_HW_ID (id 4: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and
  * HW_REG_XCC_ID (id 20, bits 3:0) -- s_getreg_b32 with (size-1) << 11 | offset << 6 | id */
 #define QP_HW_SIMD() ((int)__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4))
