@@ -256,3 +256,35 @@ def test_config2_in_kkt_mode():
     assert rel(xk[0], o.x) <= 1e-8 and rel(yk[0], o.y) <= 1e-8
     assert rel(xk[0], xs[0]) <= 1e-5 and rel(yk[0], ys[0]) <= 1e-5      # two factorisation methods, one solution (to the tolerance of the solve)
     assert np.array_equal(bk.ivec("active", 0), o.ivec("active"))
+
+
+def test_kkt_compact_factorisation_equals_the_full_one(ctx):
+    """KKT mode's form + factorise on the variables and the ACTIVE constraints only (qpalm_kkt.h: kkt_form_compact / kkt_expand,
+    round 4) against the dense factorisation of the whole (n+m) x (n+m) panel with its unit rows (ctx option kkt_compact = 0) and
+    against the oracle's KKT factor: entry by entry after a few iterations (a refactorisation with a non-trivial active set, then
+    row additions / deletions on the spread-out factor), and whole solves with identical counts and iterates."""
+    n, m = sizes(ctx, (40, 70), (160, 270))
+    p = random_qp(n, m, seed=77, density_A=max(0.02, 4.0 / n), density_M=max(0.01, 2.0 / n))
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, factorization_method=0)
+    res = {}
+    try:
+        for comp in (1, 0):
+            ctx.set_option("kkt_compact", comp)
+            bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+            bt.iterate(4)
+            Lm, D = bt.factor_rows(n + m)
+            act = bt.ivec("active")
+            bt.solve()
+            x, y = bt.solution()
+            res[comp] = (Lm, D, act, x[0].copy(), y[0].copy(), int(bt.info(0).iter), int(bt.stats(0).n_refactor))
+            bt.close()
+    finally:
+        ctx.set_option("kkt_compact", 1)
+    (L1, D1, a1, x1, y1, it1, rf1), (L0, D0, a0, x0, y0, it0, rf0) = res[1], res[0]
+    assert np.array_equal(a1, a0) and 0 < int(a1.sum()) < m          # some constraints active, some not
+    assert np.max(np.abs(D1 - D0)) <= 1e-12 * np.max(np.abs(D0)) and np.max(np.abs(np.tril(L1, -1) - np.tril(L0, -1))) <= 1e-12
+    assert (it1, rf1) == (it0, rf0) and rel(x1, x0) <= 1e-12 and rel(y1, y0) <= 1e-10
+    o = ob.OracleQP(*p.args(), settings=ob.default_settings(**dict(st, max_iter=4)))
+    o.solve()
+    Lo, Do = o.kkt_factor()
+    assert rel(D1, Do) <= 1e-9 and np.max(np.abs(np.tril(L1, -1) - np.tril(Lo, -1))) <= 1e-9
