@@ -76,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--narrow-rows", type=int, default=1, help="0: Schur assembly with one wavefront per column also for small QPs (A/B)")
     ap.add_argument("--place-panel-wave", type=int, default=1, help="0: every workgroup runs its serial chains on wavefront 0 (A/B of the SIMD placement)")
     ap.add_argument("--sweep-ranks", type=int, default=0, help="most ranks per sweep of the rank update: 16 or 32 (A/B; 0: library default = 32)")
+    ap.add_argument("--kkt-compact", type=int, default=-1, help="KKT mode: 0 = factorise the whole (n+m) panel with its unit rows (A/B; default: the active rows only)")
     ap.add_argument("--ld-align", type=int, default=0, help="leading dimension of the factor panels rounded up to this many doubles (A/B; 0: library default = 16)")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
@@ -360,6 +361,8 @@ def worker(args):
         ctx.set_option("ld_align", args.ld_align)
     if args.sweep_ranks:
         ctx.set_option("sweep_ranks", args.sweep_ranks)
+    if args.kkt_compact >= 0:
+        ctx.set_option("kkt_compact", args.kkt_compact)
     if not args.small_workgroups:
         ctx.set_option("small_workgroups", 0)
     if not args.place_panel_wave:

@@ -56,17 +56,15 @@ def build_hip(force=False, verbose=False):
 
 
 def check_device_assembly(path):
-    """Fails the build when the device assembly holds a VGPR-to-VGPR copy ahead of the `s_or_b64 exec` of its block."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("scan_exec_prologue", os.path.join(ROOT, "tools", "scan_exec_prologue.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    bad = mod.copies(mod.scan(path))
-    if bad:
+    """Fails the build when the device assembly saves a pre-region value ahead of the exec restore of its block (qpalm_amd/asm_gate.py).
+    The library that was just linked is removed: a build that trips the gate must not be loadable."""
+    from . import asm_gate
+    try:
+        asm_gate.check(path)
+    except RuntimeError:
         if os.path.exists(LIB):
             os.remove(LIB)
-        raise RuntimeError("register copies ahead of an exec restore (compiler fault, see tools/scan_exec_prologue.py):\n" +
-                           "\n".join("%s %s line %d: %s" % b for b in bad[:20]))
+        raise
 
 
 def build_host():

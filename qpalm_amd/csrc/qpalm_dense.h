@@ -1171,9 +1171,9 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   constexpr int PROWS = QP_T * RPT; /* rows per pass */
   constexpr bool MP = (K > 16);     /* several passes (the forms with at most 16 ranks run with RPT = all rows of the factor / QP_T: one pass) */
   static_assert(PROWS % NB == 0, "passes start on block boundaries");
-  /* wavefront numbering rotated so that "wavefront 0" below (panel wave, owner of the first rows) is the wavefront
-   * qp_place_panel_wave picked for this workgroup; rows are owned by the ROTATED thread id throughout the sweep */
-  const int lane = threadIdx.x & 63, wid = QP_UNIFORM((int)((threadIdx.x >> 6) - S.panel_wave) & (QP_NW - 1)), tid = wid * 64 + lane;
+  /* wavefronts renamed so that "wavefront 0" below (panel wave, owner of the first rows) is the wavefront qp_place_panel_wave picked
+   * for this workgroup (S.wave_rank, see there); rows are owned by the RENAMED thread id throughout the sweep */
+  const int lane = threadIdx.x & 63, wid = QP_UNIFORM(S.wave_rank[threadIdx.x >> 6]), tid = wid * 64 + lane;
   const int nr_all = n_up + n_dn;
   const int rk1 = (rkn < nr_all - rk0) ? (rk0 + rkn) : nr_all; /* ranks [rk0, rk1) */
   qp_gdouble *dummy = Wst + (size_t)QPG_KWST * n;

@@ -167,6 +167,8 @@ struct QpShared {          /* small static LDS block */
   int    hw_simd[QP_NW];   /* SIMD each wavefront of this workgroup sits on */
   int    placement;        /* diagnostic code of the placement (QPGStats.placement) */
   int    panel_wave;       /* the wavefront that runs the serial chains of the update sweep (qp_place_panel_wave) */
+  int    wave_rank[QP_NW]; /* the sweep's name for each hardware wavefront: 0 = panel wave (owner of the first rows), then the wavefronts that
+                              sit on the SIMDs where the CU's panel waves run (they get the rows that retire first), then the rest */
 };
 
 QPD double wave_sum(double v) {

@@ -270,6 +270,21 @@ QPD void qp_place_panel_wave(const qpg_view &V, QpShared &S) {
     for (int w = QP_NW - 1; w >= 0; w--) if (S.hw_simd[w] == target) pw = w;
     S.panel_wave = V.place_panel_wave ? pw : 0;
     S.placement = key << 16 | (arrival & 255) << 8 | S.panel_wave << 4 | S.hw_simd[0];
+    /* Row ownership follows the SIMDs (place_panel_wave = 2): the sweep's wavefront w owns rows [w RPT 64, (w+1) RPT 64), which retire
+     * in that order.  The panel waves of the two workgroups of a CU run on SIMDs 0 and 1: the wavefronts that share those SIMDs with
+     * them get the ranks right after the panel wave, i.e. the rows that retire first, so that in the second half of every sweep the
+     * serial chains have their SIMDs to themselves (measured alone vs loaded: 51 vs 57 ms per QP of panel-wave time).  Results do
+     * not depend on who owns which rows. */
+    if (V.place_panel_wave >= 2 && QP_NW >= 8) {
+      int r = 0;
+      S.wave_rank[S.panel_wave] = r++;
+      const int s0 = S.hw_simd[S.panel_wave];
+      for (int w = 0; w < QP_NW; w++) if (w != S.panel_wave && S.hw_simd[w] == s0) S.wave_rank[w] = r++;
+      for (int w = 0; w < QP_NW; w++) if (S.hw_simd[w] == (s0 ^ 1)) S.wave_rank[w] = r++;
+      for (int w = 0; w < QP_NW; w++) if ((S.hw_simd[w] | 1) != (s0 | 1)) S.wave_rank[w] = r++;
+    } else {
+      for (int w = 0; w < QP_NW; w++) S.wave_rank[w] = (w - S.panel_wave) & (QP_NW - 1);
+    }
   }
   __syncthreads();
 }
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
   const QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x, slot = b;
   double *L = V.L + (size_t)slot * V.ld * V.nfac, *Dg = V.Dg + (size_t)slot * V.nfac, *Wst = V.Wst + (size_t)slot * V.wst_stride;
-  if (tid == 0) { I.s = V.sc[b]; I.S.panel_wave = 0; I.S.placement = 0; }
+  if (tid == 0) { I.s = V.sc[b]; I.S.panel_wave = 0; I.S.placement = 0; for (int w = 0; w < QP_NW; w++) I.S.wave_rank[w] = w; }
   __syncthreads();
   switch (op) {
     case QP_OP_MATVEC_A: spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), V.op_in, [&](int r, double s) { V.op_out[r] = s; }); break;
