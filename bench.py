@@ -74,7 +74,7 @@ def parse_args(argv=None):
                                                         "(what BASELINE.json config 3 literally names) instead of the Schur panel with rank updates")
     ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
     ap.add_argument("--narrow-rows", type=int, default=1, help="0: Schur assembly with one wavefront per column also for small QPs (A/B)")
-    ap.add_argument("--place-panel-wave", type=int, default=1, help="0: every workgroup runs its serial chains on wavefront 0 (A/B of the SIMD placement)")
+    ap.add_argument("--place-panel-wave", type=int, default=-1, help="0: every workgroup runs its serial chains on wavefront 0; 1: panel waves placed on SIMDs 0 / 1; 2: + row ownership by SIMD (A/B; default: the library's)")
     ap.add_argument("--sweep-ranks", type=int, default=0, help="most ranks per sweep of the rank update: 16 or 32 (A/B; 0: library default = 32)")
     ap.add_argument("--kkt-compact", type=int, default=-1, help="KKT mode: 0 = factorise the whole (n+m) panel with its unit rows (A/B; default: the active rows only)")
     ap.add_argument("--ld-align", type=int, default=0, help="leading dimension of the factor panels rounded up to this many doubles (A/B; 0: library default = 16)")
@@ -365,8 +365,8 @@ def worker(args):
         ctx.set_option("kkt_compact", args.kkt_compact)
     if not args.small_workgroups:
         ctx.set_option("small_workgroups", 0)
-    if not args.place_panel_wave:
-        ctx.set_option("place_panel_wave", 0)
+    if args.place_panel_wave >= 0:
+        ctx.set_option("place_panel_wave", args.place_panel_wave)
     if not args.narrow_rows:
         ctx.set_option("narrow_rows", 0)
     B = args.batch

@@ -54,6 +54,9 @@ def ctx(request):
     c.kind = kind
     c.set_option("update_rank_threshold", -1)
     c.set_option("max_slots", 512)
+    c.set_option("place_panel_wave", 0)
+    c.set_option("sweep_ranks", 16)
+    c.set_option("kkt_compact", 1)
     c.set_option("coop", 0)              # the one-workgroup-per-QP engine; tests/test_coop.py switches the multi-workgroup mode on
     c.set_option("coop_workgroups", 3 if kind == "emu" else 256)
     return c

@@ -563,7 +563,7 @@ def test_workgroup_shapes_and_placement_do_not_change_results(ctx):
     probs = [random_qp(n, m, seed=5100 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(sizes(ctx, 2, 6))]
     st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     try:
-        for small, place in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        for small, place in ((1, 1), (0, 1), (1, 0), (0, 0), (0, 2)):   # place 2: rows owned by SIMD (512-thread instance)
             ctx.set_option("small_workgroups", small)
             ctx.set_option("place_panel_wave", place)
             bt = _compare_solve(ctx, probs, st)
@@ -573,7 +573,7 @@ def test_workgroup_shapes_and_placement_do_not_change_results(ctx):
                 assert threads == (256 if small else 512)
     finally:
         ctx.set_option("small_workgroups", 1)
-        ctx.set_option("place_panel_wave", 1)
+        ctx.set_option("place_panel_wave", 0)
 
 
 def _with_long_row_and_column(p, seed):
