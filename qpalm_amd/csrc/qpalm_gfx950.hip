@@ -72,11 +72,16 @@ static int rt_device_init(int device, std::string &why) {
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { why = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"; return 1; }
   return 0;
 }
-#include <unordered_map>
-template <class K> static void rt_allow_lds(K kernel, size_t shmem) { /* once per kernel and size (the attribute call is not free: coop mode launches thousands of kernels) */
+#include <map>
+#include <mutex>
+template <class K> static void rt_allow_lds(K kernel, size_t shmem) { /* once per (device, kernel) and size (the attribute call is not free: coop mode launches thousands of kernels) */
   if (shmem <= 48 * 1024) return;
-  static std::unordered_map<const void *, size_t> granted;
-  size_t &g = granted[(const void *)kernel];
+  static std::map<std::pair<int, const void *>, size_t> granted;
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &g = granted[std::make_pair(dev, (const void *)kernel)];
   if (g >= shmem) return;
   (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   g = shmem;
@@ -94,9 +99,9 @@ template <class K> static void rt_allow_lds(K kernel, size_t shmem) { /* once pe
 #define RT_MEMSET(dst, val, bytes) rt_check(hipMemset((void *)(dst), (val), (bytes)), "hipMemset")
 /* asynchronous uploads from page-locked staging on a copy stream of their own; RT_COPY_MARK(k) records "everything issued so far" for
  * staging buffer k, RT_COPY_WAIT(k) waits for it on the host */
-static hipStream_t g_rt_copy_stream = 0;
-static hipEvent_t g_rt_copy_event[2] = {0, 0};
-static int g_rt_copy_marked[2] = {0, 0};
+static thread_local hipStream_t g_rt_copy_stream = 0;
+static thread_local hipEvent_t g_rt_copy_event[2] = {0, 0};
+static thread_local int g_rt_copy_marked[2] = {0, 0};
 static int rt_copy_async(void *dst, const void *src, size_t bytes) {
   if (!g_rt_copy_stream && rt_check(hipStreamCreateWithFlags(&g_rt_copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return 1;
   return rt_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_rt_copy_stream), "hipMemcpyAsync H2D");
@@ -116,8 +121,10 @@ static void rt_copy_wait(int k) {
 #define RT_STICKY() (g_rt_sticky)
 #define RT_STICKY_CLEAR() (g_rt_sticky = 0)
 #define RT_LAST_ERROR() (g_rt_err.c_str())
-/* launches go to g_rt_stream: the null stream, or the capturing stream while a launch sequence is recorded into a graph */
-static hipStream_t g_rt_stream = 0, g_rt_capture_stream = 0;
+/* launches go to g_rt_stream: the null stream, or the capturing stream while a launch sequence is recorded into a graph.  The capture
+ * state is per host thread: while one thread records a coop launch chain, launches of another thread (another batch / context) keep
+ * going to the null stream instead of being recorded into the wrong graph. */
+static thread_local hipStream_t g_rt_stream = 0, g_rt_capture_stream = 0;
 #define RT_LAUNCH(kernel, grid, block, shmem, ...)                                         \
   do {                                                                                      \
     rt_allow_lds(kernel, (shmem));                                                          \

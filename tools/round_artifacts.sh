@@ -1,36 +1,37 @@
 #!/bin/bash
 # Round evidence, run on the GPU box:  bash tools/round_artifacts.sh [round]   (outputs under gpurun_out/<round>/final/)
-# Copies to profiles/<round>/ are made by hand from the merged gpurun_out/.
-R=${1:-r03}
+# Copies to profiles/<round>/ are made by hand from the merged gpurun_out/.  Every step has its own timeout.
+R=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/$R/final
 mkdir -p $OUT
 cd $REPO
-python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
+timeout 900 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel trace (own run) and the PMC passes (separate runs, counters only), all of the default bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --no-cpu > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktm -- python3 $REPO/bench.py --workload mpc-160 --steps 5 --no-cpu > $OUT/bench_mpc160_under_kernel_trace.json 2> $OUT/ktm.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktk -- python3 $REPO/bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt_under_kernel_trace.json 2> $OUT/ktk.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktc -- python3 $REPO/tools/coop_timing.py 2500 > $OUT/coop_timing_n2500_under_kernel_trace.txt 2> $OUT/ktc.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --no-cpu --no-mpc > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-mpc > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-mpc > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-mpc > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktm -- python3 $REPO/bench.py --workload mpc-160 --steps 5 --no-cpu > $OUT/bench_mpc160_under_kernel_trace.json 2> $OUT/ktm.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktk -- python3 $REPO/bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt_under_kernel_trace.json 2> $OUT/ktk.err
 cd $OUT
 find kt -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_default.csv \;
 find ktm -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_mpc160.csv \;
 find ktk -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_mpc160_kkt.csv \;
-find ktc -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_coop_n2500.csv \;
 python3 $REPO/tools/pmc_summary.py $OUT $REPO > $OUT/k_solve_pmc_traffic.json
-rm -rf kt ktm ktk ktc pmc_fetch pmc_write pmc_sq
+rm -rf kt ktm ktk pmc_fetch pmc_write pmc_sq
 cd $REPO
 # the reported line: same build, same box, traffic from the passes above (bench.py checks the source and library hashes recorded in the summary)
-python bench.py --traffic-json $OUT/k_solve_pmc_traffic.json > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --batch 512 --no-cpu > $OUT/bench_b512.json 2>> $OUT/bench_default.err
-python bench.py --workload mpc-160 --steps 5 > $OUT/bench_mpc160.json 2>> $OUT/bench_default.err
-python bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt.json 2>> $OUT/bench_default.err
-python tools/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_probe.txt 2>> $OUT/bench_default.err
-python tools/coop_timing.py 512 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
-python tools/coop_config5.py 5000 > $OUT/coop_config5.txt 2>&1
+timeout 1200 python bench.py --traffic-json $OUT/k_solve_pmc_traffic.json > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 600 python bench.py --batch 512 --no-cpu --no-mpc > $OUT/bench_b512.json 2>> $OUT/bench_default.err
+timeout 600 python bench.py --workload mpc-160 --steps 5 > $OUT/bench_mpc160.json 2>> $OUT/bench_default.err
+timeout 600 python bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt.json 2>> $OUT/bench_default.err
+timeout 600 python bench.py --sweep-ranks 32 --no-cpu --no-mpc > $OUT/bench_sweep_ranks_32.json 2>> $OUT/bench_default.err
+bash tools/phase_traffic.sh $R/final/phase_traffic > $OUT/phase_traffic.log 2>&1
+timeout 300 python tools/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_probe.txt 2>> $OUT/bench_default.err
+timeout 300 python tools/setup_timing.py 8192 > $OUT/setup_timing.txt 2>&1
+timeout 600 python tools/coop_timing.py 512 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
+timeout 300 tools/sload_coherence_test > $OUT/sload_coherence.txt 2>&1
 ls -la $OUT
