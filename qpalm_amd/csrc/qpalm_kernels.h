@@ -33,6 +33,7 @@
 #define QP_OP_KKT_ENTER 16
 #define QP_OP_KKT_LEAVE 17
 #define QP_OP_KKT_SOLVE 18
+#define QP_OP_KKT_EXPAND 19 /* a compact KKT factor spread out to the full (n+m) layout (before the host reads it) */
 
 /* qpalm_setup's device part: Ruiz scaling (scaling.c:34-113) and derived copies.
  * mode 0: fresh setup (nscale iterations); mode 1: qpalm_update_settings with more scaling
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
     case QP_OP_KKT_ENTER: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 2, I.s.nb_enter, 0, 0); break;
     case QP_OP_KKT_LEAVE: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 2, 0, I.s.nb_leave, 0); break;
     case QP_OP_KKT_SOLVE: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 0, 0, 0, QP_KKT_SOLVE); break;
+    case QP_OP_KKT_EXPAND: if (V.kkt) kkt_newton<RPT>(&V, b, L, Dg, Wst, &I, lds, 5, 0, 0, 0); break;
     default: break;
   }
   __syncthreads();

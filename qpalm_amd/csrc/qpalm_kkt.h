@@ -169,7 +169,7 @@ QPD void kkt_residual(const qpg_view &V, const QpArrays &a, int b, IterShared &I
 
 /* The KKT branch.  action: 1 (re)form + factorise (qpalm_form_kkt / qpalm_reform_kkt + ladel_factorize*), 2 row additions for
  * enter[0 .. ne) then row deletions for leave[0 .. nl) (kkt_update_entering_constraints / kkt_update_leaving_constraints),
- * 3 form only, 4 factorise what the slot holds, 0 keep.  flags: 1 kkt_solve (solver_interface.c:238-247), 2 the iterative
+ * 3 form only, 4 factorise what the slot holds, 5 spread a compact factor out to the full layout, 0 keep.  flags: 1 kkt_solve (solver_interface.c:238-247), 2 the iterative
  * refinement of newton.c:57-90 on top of it.  One Newton step = (action, nb_enter, nb_leave, 3); the boundary operations of
  * include/qpalm_gfx950.h (qpg_kkt_*) call the pieces one by one. */
 #define QP_KKT_SOLVE 1
@@ -186,17 +186,23 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
   const size_t sk = (size_t)V.n + V.m; /* batch strides */
   double *sol = V.kkt_sol + (size_t)b * sk, *rhs = V.kkt_rhs + (size_t)b * sk, *z = V.kkt_tmp + (size_t)b * sk;
   int *state = V.kkt_state + (size_t)b * V.m;
-  /* the solver's "form + factorise" works on the active rows only when the staging of the spreading step fits the LDS */
-  const bool compact = (action == 1) && V.kkt_compact && ((size_t)QP_NW * np * sizeof(double) + (size_t)m * sizeof(int) <= (size_t)V.lds_bytes);
-  if (compact) {
-    int *list = a.ls_idx(); /* line-search scratch, idle here: [0, m) the active constraints ascending */
-    const int na = kkt_form_compact(V, a, b, L, gamma, prox, I, list);
-    dense_factor<RPT>(L, Dg, n + na, ld, lds, I.s.ticks_dbg);
-    kkt_expand(V, a, L, Dg, na, list, lds);
+  /* The solver's "form + factorise" works on the active rows only (when the staging of the spreading step fits the LDS), and the
+   * factor STAYS compact -- the solves run on it, half the rows -- until a row addition / deletion or a read of the factor needs
+   * the full layout (kkt_expand then; I.s.kkt_na says which layout the slot holds). */
+  int *list = V.kkt_list + (size_t)b * V.m;
+  const bool can_compact = V.kkt_compact && ((size_t)QP_NW * np * sizeof(double) + (size_t)m * sizeof(int) <= (size_t)V.lds_bytes);
+  int kna = QP_UNIFORM(I.s.kkt_na);
+  if (action == 1 && can_compact) {
+    kna = kkt_form_compact(V, a, b, L, gamma, prox, I, list);
+    dense_factor<RPT>(L, Dg, n + kna, ld, lds, I.s.ticks_dbg);
   } else {
-  if (action == 1 || action == 3) kkt_form(V, a, b, L, gamma, prox);
-  if (action == 1 || action == 4) dense_factor<RPT>(L, Dg, np, ld, lds, I.s.ticks_dbg);
+    if (kna >= 0 && (action == 2 || action == 5)) { kkt_expand(V, a, L, Dg, kna, list, lds); kna = -1; } /* 5: only make the layout full (a read of the factor) */
+    if (action == 1 || action == 3) { kkt_form(V, a, b, L, gamma, prox); kna = -1; }
+    if (action == 1 || action == 4) { dense_factor<RPT>(L, Dg, np, ld, lds, I.s.ticks_dbg); kna = -1; }
   }
+  __syncthreads();
+  if (tid == 0) I.s.kkt_na = kna;
+  __syncthreads();
   if (action == 2) {
     for (int e = 0; e < ne + nl; e++) {
       const bool add = e < ne;
@@ -267,11 +273,22 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
     if (tid == 0) I.s.n_rank1 += ne + nl;
   }
   if (!(flags & QP_KKT_SOLVE)) { __syncthreads(); return; }
-  /* kkt_solve (solver_interface.c:238-247) */
+  /* kkt_solve (solver_interface.c:238-247).  On the compact factor: the right-hand side / solution of the listed constraints sit behind the
+   * variables in a work vector; an inactive constraint's row of K is a unit row, its solution is its right-hand side. */
   __syncthreads();
+  auto solve_in_place = [&](double *v) QP_ALWAYS_INLINE { /* v (full layout, n + m) <- K^{-1} v with the factor the slot holds */
+    if (kna < 0) { dense_solve(L, Dg, np, ld, v, lds, V.lds_bytes, I.s.ticks_dbg); return; }
+    double *w = V.kkt_rhs2 + (size_t)b * sk; /* compact right-hand side */
+    __syncthreads();
+    for (int j = tid; j < n + kna; j += QP_T) w[j] = (j < n) ? v[j] : v[n + list[j - n]];
+    __syncthreads();
+    dense_solve(L, Dg, n + kna, ld, w, lds, V.lds_bytes, I.s.ticks_dbg);
+    for (int j = tid; j < n + kna; j += QP_T) { if (j < n) v[j] = w[j]; else v[n + list[j - n]] = w[j]; } /* the other constraints keep v = rhs (unit rows) */
+    __syncthreads();
+  };
   for (int j = tid; j < np; j += QP_T) sol[j] = (j < n) ? a.dphi()[j] * -1 : 0.0;
   __syncthreads();
-  dense_solve(L, Dg, np, ld, sol, lds, V.lds_bytes, I.s.ticks_dbg);
+  solve_in_place(sol);
   for (int j = tid; j < n; j += QP_T) a.d()[j] = sol[j];
   if (!(flags & QP_KKT_REFINE)) { __syncthreads(); return; }
   /* iterative refinement (newton.c:57-90; constants.h:101-103) */
@@ -287,7 +304,7 @@ QPNI void kkt_newton(const qpg_view *Vp, int b_, double *L, double *Dg, double *
     __syncthreads();
     for (int j = tid; j < np; j += QP_T) z[j] = rhs[j]; /* the correction solve works in place on a copy */
     __syncthreads();
-    dense_solve(L, Dg, np, ld, z, lds, V.lds_bytes, I.s.ticks_dbg);
+    solve_in_place(z);
     for (int j = tid; j < np; j += QP_T) {
       const double dz = z[j];
       if (j < n) a.d()[j] = dz + 1 * a.d()[j];

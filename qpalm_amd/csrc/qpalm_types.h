@@ -67,7 +67,9 @@ typedef struct {
   /* "coop" mode (one large QP, the linear algebra spread over many workgroups by the host, qpalm_capi.inc: coop_solve): the
    * iteration is suspended at its linear-algebra site.  pend_stage = 1: the host has to factorise (pend_la = 1 Q + A'SA, 3 Q only,
    * 7 LD_Q of the dual objective; 0 no factorisation) and, for a Newton step (pend_kind == 0, pend_la != 7), to solve for d */
-  int32_t pend_stage, pend_la, pend_action, pend_kind, pend_nchange, pend_pad;
+  int32_t pend_stage, pend_la, pend_action, pend_kind, pend_nchange;
+  int32_t kkt_na; /* KKT mode: -1 = the factor slot holds the full (n+m) layout; na >= 0 = the COMPACT factor of the variables + the na constraints listed
+                     in kkt_list (the factor is spread out only when a row addition / deletion or a read of the factor needs the full layout) */
   double pend_gam;
   int64_t pend_clock; /* device clock (100 MHz, the same counter in every launch) when the iteration was suspended: the time the host's
                          kernels take until it resumes is added to solve_time, so that run_time and time_limit see wall time (qpalm.c:680-723) */
@@ -109,8 +111,9 @@ typedef struct {
                   allocated only when enable_dual_termination is set, else NULL */
   double *DgQ; /* [nslots][n] */
   double *dual_rhs; /* [B][n] Aty + q (the reference uses neg_dphi for it, iteration.c:276) */
-  double *kkt_sol, *kkt_rhs, *kkt_tmp; /* [B][n+m] sol_kkt / rhs_kkt of the KKT path (qpalm.c:241-242) + scratch; NULL in Schur mode */
+  double *kkt_sol, *kkt_rhs, *kkt_tmp, *kkt_rhs2; /* [B][n+m] sol_kkt / rhs_kkt of the KKT path (qpalm.c:241-242) + scratch (kkt_rhs2: the compact right-hand side); NULL in Schur mode */
   int32_t *nq, *mq;   /* [B] per-QP dimensions (<= n, m: members of a mixed-size batch are padded to the batch strides); NULL = uniform */
+  int32_t *kkt_list;  /* [B][m] the active constraints (ascending) the compact KKT factor was formed with (qpg_scalars.kkt_na) */
   int32_t *kkt_state; /* [B][m] 0 unit diagonal, 1 row present, 2 deleted by row_del (solver_interface.c:151-156,226-235) */
   double *Wst; /* [nslots][wst_stride]: staging of the rank-update vectors, dummy cells, exported tables (QPG_WST_STRIDE) */
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
