@@ -89,6 +89,7 @@ template <class K> static void rt_allow_lds(K kernel, size_t shmem) { /* once pe
 
 #define RT_BACKEND_NAME "gfx950-hip"
 #define RT_DEVICE_INIT(device, why) rt_device_init((device), (why))
+#define RT_THREAD_DEVICE(device) (void)hipSetDevice(device) /* the current device is per host thread */
 #define RT_MALLOC(pp, bytes) rt_check(hipMalloc((void **)(pp), (bytes)), "hipMalloc")
 #define RT_FREE(p) (void)hipFree(p)
 #define RT_HOST_ALLOC(pp, bytes) rt_check(hipHostMalloc((void **)(pp), (bytes), hipHostMallocDefault), "hipHostMalloc")

@@ -16,6 +16,7 @@ static int rt_malloc(void **pp, size_t bytes) { *pp = calloc(bytes ? bytes : 1, 
 
 #define RT_BACKEND_NAME "host-emulation"
 #define RT_DEVICE_INIT(device, why) rt_device_init((device), (why))
+#define RT_THREAD_DEVICE(device) (void)(device)
 #define RT_MALLOC(pp, bytes) rt_malloc((void **)(pp), (bytes))
 #define RT_FREE(p) free(p)
 #define RT_HOST_ALLOC(pp, bytes) rt_malloc((void **)(pp), (bytes))
@@ -24,7 +25,7 @@ static int rt_malloc(void **pp, size_t bytes) { *pp = calloc(bytes ? bytes : 1, 
 #define RT_MEMCPY_D2H(dst, src, bytes) memcpy((void *)(dst), (const void *)(src), (bytes))
 #define RT_MEMCPY2D_H2D(dst, dpitch, src, spitch, width, height) do { for (size_t r_ = 0; r_ < (size_t)(height); r_++) memcpy((char *)(dst) + r_ * (dpitch), (const char *)(src) + r_ * (spitch), (width)); } while (0)
 #define RT_MEMSET(dst, val, bytes) memset((void *)(dst), (val), (bytes))
-#define RT_MEMCPY_H2D_ASYNC(dst, src, bytes, k) memcpy((void *)(dst), (const void *)(src), (bytes))
+#define RT_MEMCPY_H2D_ASYNC(dst, src, bytes, k) (memcpy((void *)(dst), (const void *)(src), (bytes)), 0)
 #define RT_COPY_MARK(k) do { } while (0)
 #define RT_COPY_WAIT(k) do { } while (0)
 #define RT_SYNC() 0

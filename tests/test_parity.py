@@ -628,6 +628,31 @@ def test_no_constraints_and_single_constraint(ctx):
     _compare_solve(ctx, [p1], st)
 
 
+def test_replacing_a_member_and_setting_up_again(ctx):
+    """qpg_batch_set_problem on a member that is already set (fewer nonzeros, other values) followed by a second qpg_batch_setup: the
+    batch then solves exactly what a fresh batch of the new members solves (the host slab's padding behind the shorter arrays and the
+    device arena are cleared)."""
+    from qpalm_amd.capi import f64, fptr, i64, iptr
+    dense = [random_qp(24, 30, seed=50 + k, density_A=0.5, density_M=0.4) for k in range(3)]
+    thin = [random_qp(24, 30, seed=60 + k, density_A=0.1, density_M=0.05) for k in range(3)]
+    st = dict(eps_abs=1e-8, eps_rel=1e-8, verbose=0)
+    nzA, nzQ = max(int(p.Ap[-1]) for p in dense), max(int(p.Qp[-1]) for p in dense)
+    assert all(int(p.Ap[-1]) < nzA and int(p.Qp[-1]) < nzQ for p in thin)
+    bt = QpalmBatch(ctx, dense, ctx.default_settings(**st))
+    bt.solve()
+    for k, p in enumerate(thin):
+        a = (i64(p.Qp), i64(p.Qi), f64(p.Qx), i64(p.Ap), i64(p.Ai), f64(p.Ax), f64(p.q), f64(p.bmin), f64(p.bmax))
+        bt._check(bt.L.qpg_batch_set_problem(bt.h, k, iptr(a[0]), iptr(a[1]), fptr(a[2]), iptr(a[3]), iptr(a[4]), fptr(a[5]), fptr(a[6]), 0.0, fptr(a[7]), fptr(a[8])))
+    bt._check(bt.L.qpg_batch_setup(bt.h))
+    bt.solve()
+    fresh = QpalmBatch(ctx, thin, ctx.default_settings(**st))
+    fresh.solve()
+    for got, want in zip(bt.solution(), fresh.solution()):
+        assert np.array_equal(got, want)
+    assert [i.iter for i in bt.infos()] == [i.iter for i in fresh.infos()]
+    _compare_solve(ctx, thin, st)
+
+
 def test_mpc_qps_match_oracle(ctx):
     T = sizes(ctx, 3, 10)
     probs = [random_mpc_qp(T=T, nx=sizes(ctx, 4, 10), nu=sizes(ctx, 2, 5), seed=k) for k in range(2)]

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Prints the figures of an evidence set (profiles/<round>/final/, written by tools/round_artifacts.sh) that DESIGN.md section 4 quotes,
-so that the table there is copied from the files and not retyped.  usage: evidence_table.py [profiles/r03/final]"""
+so that the table there is copied from the files and not retyped.  usage: evidence_table.py [profiles/r04/final]"""
 import csv
 import json
 import os
 import re
 import sys
 
-d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03", "final")
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04", "final")
 J = lambda f: json.load(open(os.path.join(d, f)))
 b = J("bench_default.json")
 r, st = b["roofline"], b["solve_stats"]
@@ -36,10 +36,32 @@ print("mpc-160 %.0f QP/s (%.1f ms per step); kkt %.0f QP/s (%.1f ms); B=512 %.0f
 c, cm = b["cpu_baseline"], m["cpu_baseline"]
 print("cpu n=1000: %.0f QP/s on %d threads, tried %s, alone %.3f s, loaded %.2f s, wall %.0f s; mpc-160: %.0f QP/s on %d threads, tried %s" % (
     c["value"], c["cores"], c["threads_tried_qps"], c["single_qp_alone_s"], c["setup_plus_solve_s_per_qp"], c["wall_s"], cm["value"], cm["cores"], cm["threads_tried_qps"]))
-print(open(os.path.join(d, "coop_timing.txt")).read().strip())
-print("\n".join(l for l in open(os.path.join(d, "coop_config5.txt")).read().splitlines() if "amdgpu" not in l))
-for x in csv.DictReader(open(os.path.join(d, "rocprofv3_kernel_stats_coop_n2500.csv"))):
-    if "k_co_" in x["Name"]:
-        print("   %-28s %6s calls, %.1f us average" % (re.sub(r"\(.*", "", x["Name"]).replace("qp512::", ""), x["Calls"], float(x["AverageNs"]) * 1e-3))
-print(open(os.path.join(d, "sweep_probe.txt")).read().strip())
+def opt(name):
+    pth = os.path.join(d, name)
+    return open(pth).read().strip() if os.path.exists(pth) else "(%s: not in this evidence set)" % name
+print("\n".join(l for l in opt("coop_timing.txt").splitlines() if "amdgpu" not in l))
+if os.path.exists(os.path.join(d, "coop_config5.txt")):
+    print("\n".join(l for l in open(os.path.join(d, "coop_config5.txt")).read().splitlines() if "amdgpu" not in l))
+if os.path.exists(os.path.join(d, "rocprofv3_kernel_stats_coop_n2500.csv")):
+    for x in csv.DictReader(open(os.path.join(d, "rocprofv3_kernel_stats_coop_n2500.csv"))):
+        if "k_co_" in x["Name"]:
+            print("   %-28s %6s calls, %.1f us average" % (re.sub(r"\(.*", "", x["Name"]).replace("qp512::", ""), x["Calls"], float(x["AverageNs"]) * 1e-3))
+print(opt("sweep_probe.txt"))
+if "mpc160" in b:
+    for k in ("schur", "kkt"):
+        mm = b["mpc160"].get(k, {})
+        if "value" in mm:
+            print("default line, mpc160.%s: %.0f QP/s (%.2f ms per step, kernel %.2f)" % (k, mm["value"], mm["ms_per_step"], mm["kernel_ms_per_step"]))
+if os.path.exists(os.path.join(d, "bench_sweep_ranks_32.json")):
+    s32 = J("bench_sweep_ranks_32.json")
+    print("sweep_ranks 32: %.0f QP/s, frac %.3f, needed %.3f TB, sweeps per QP %.1f, hash %s (default: %s)" % (
+        s32["value"], s32["roofline"]["frac"], s32["roofline"]["algorithmic_bytes_per_launch"] * 1e-12, s32["solve_stats"]["per_qp_mean"]["n_sweeps"],
+        s32["solve_stats"]["solution_sha256_16"], st["solution_sha256_16"]))
+print("\n".join(l for l in opt("setup_timing.txt").splitlines() if "amdgpu" not in l))
+if os.path.exists(os.path.join(d, "phase_traffic", "phase_traffic.json")):
+    pt = json.load(open(os.path.join(d, "phase_traffic", "phase_traffic.json")))
+    for k in ("factor", "sweep16", "sweep8", "sweep64", "solve"):
+        if k in pt:
+            print("phase traffic %-8s read %.2f write %.2f MB per QP, moved / needed %.3f" % (k, pt[k]["read"], pt[k]["write"], pt[k]["moved_over_needed"]))
+print(opt("sload_coherence.txt"))
 print(open(os.path.join(d, "pytest_gpu.log")).read().strip().splitlines()[-1])

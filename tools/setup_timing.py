@@ -28,15 +28,21 @@ for b, p in enumerate(probs):
     for k, a in enumerate(arrs):
         cols[k][b] = a.ctypes.data
 print("python side (pointer arrays) %.3f s" % (time.perf_counter() - t0))
-for th in ("1", "8", "32", "64"):
-    os.environ["QPALM_HOST_THREADS"] = th
+for th in ("1", "8", "16", "32", "64", "default"):
+    if th == "default":
+        os.environ.pop("QPALM_HOST_THREADS", None)
+    else:
+        os.environ["QPALM_HOST_THREADS"] = th
     h = C.c_void_p()
     st = ctx.default_settings(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
-    assert L.qpg_batch_create(ctx.h, B, 1000, 2000, 20000, 6000, C.byref(st), C.byref(h)) == 0
+    t0 = time.perf_counter()
+    assert L.qpg_batch_create(ctx.h, B, 1000, 2000, 20000, 6000, C.byref(st), C.byref(h)) == 0   # (starts the device arena allocation on a thread)
     t1 = time.perf_counter()
     rc = L.qpg_batch_set_problems(h, 0, B, None, None, *cols[:7], None, cols[7], cols[8])
     t2 = time.perf_counter()
     rc2 = L.qpg_batch_setup(h)
     t3 = time.perf_counter()
-    print("host threads %2s: set_problems %.3f s (rc %d), batch_setup %.3f s (rc %d)" % (th, t2 - t1, rc, t3 - t2, rc2))
+    print("host threads %7s: create %.3f s, set_problems %.3f s (rc %d), batch_setup %.3f s (rc %d), total %.3f s" % (th, t1 - t0, t2 - t1, rc, t3 - t2, rc2, t3 - t0))
+    t4 = time.perf_counter()
     L.qpg_batch_destroy(h)
+    print("                       destroy %.3f s" % (time.perf_counter() - t4))
