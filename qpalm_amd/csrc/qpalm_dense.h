@@ -1581,6 +1581,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16>(nwv[1], ngam[1], wrow, l);
             }
             if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;
+            if (QP_PANEL_TIMING == 2) { double ll = l; QP_OPAQUE_V(ll); const long long t = QP_CLOCK(); if (lane == 0) tdbg[11] += t - tc0; }
           } else {
             static_assert(QP_RECUR_DPP || G == 1, "the LDS form of the recurrence handles one rank group");
             double l = lcur;
