@@ -1112,6 +1112,13 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
 #ifndef QP_RECUR_DPP
 #define QP_RECUR_DPP 1
 #endif
+#ifndef QP_OWN_A
+#define QP_OWN_A 1 /* staged square (QP_USQ): the entries L(rows of block s, columns of block s-1) are finished and written to HBM by the OWNERS of
+                      those rows, which apply table s-1 to them like to every other row below; the panel wave applies the same table to its LDS
+                      copy for the running w it needs (same FMAs in the same order: the same bits) and stores nothing.  Its one global store
+                      per column waited ~100 ns to be accepted by the CU's memory pipeline next to the owners' streams -- longer than the
+                      column's FMAs (tools/variants/README.md, "panel store probes": 312 -> 219 us per sweep with the store left out). */
+#endif
 #ifndef QP_SQ_WB
 #define QP_SQ_WB 0 /* 1 (measured in round 4: no gain, 5186-5191 against 5206-5216 QP/s same box): the panel wave writes the entries of the staged square back into LDS, not to HBM (see its loop) */
 #endif
@@ -1389,17 +1396,19 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
       const int jbn = (R1 - Jn < NB) ? ((R1 - Jn > 0) ? (R1 - Jn) : 0) : NB; /* 0 when block s is the last one of the pass */
       const int cur = s & 1, prv = cur ^ 1;
       long long tpe = QP_CLOCK();
-      const bool own_live0 = (R0 + 64 * RPT - 1 >= Jn); /* wavefront 0 still owns rows the owners work on */
+      constexpr bool OWNA = QP_OWN_A && QP_USQ && !QP_SQ_WB;
+      const int Ja = (OWNA && s > 0) ? J : Jn; /* first row the owners apply table s-1 to */
+      const bool own_live0 = (R0 + 64 * RPT - 1 >= Ja); /* wavefront 0 still owns rows the owners work on */
       auto owner_block = [&]() QP_ALWAYS_INLINE {
         /* ===== owners: table s-1 on the rows below block s, then the rows of block s+1 to the hand-over buffer ========= */
         const long long tt0 = QP_CLOCK();
         bool any = false;
 #pragma unroll
-        for (int rr = 0; rr < RPT; rr++) { const int i = R0 + tid * RPT + rr; any = any || (i >= Jn && i < R1); }
+        for (int rr = 0; rr < RPT; rr++) { const int i = R0 + tid * RPT + rr; any = any || (i >= Ja && i < R1); }
         constexpr bool WAVES = MP && QP_OWNER_DPP32; /* DPP form: whole wavefronts take part (idle lanes work on their dummy cell) */
         if (s > 0 && (WAVES ? (__ballot(any ? 1 : 0) != 0ull) : any)) {
           const int i0 = R0 + tid * RPT;
-          apply_table(prv, Jp, i0 >= Jn && i0 < rlim);
+          apply_table(prv, Jp, i0 >= Ja && i0 < rlim);
         }
         /* rows of block s+1 to the hand-over buffer of the next phase */
 #pragma unroll
@@ -1497,7 +1506,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
                * behind the owners' streaming loads and stores in the CU's memory pipeline (round 3's knock-outs: the owners' HBM traffic,
                * not their FMAs or LDS reads, slowed this loop by a third). */
               if (PSQ && QP_SQ_WB) { if (lane < NB) U.Lsq[cur][c1][lrow] = l; }
-              else rowp[(size_t)c1 * cstride] = l;
+              else if (!OWNA) rowp[(size_t)c1 * cstride] = l; /* (OWNA: the rows' owners write the entry) */
               if (fuse) accp = QP_FMA(-l, U.ys[prv][c1], accp); /* column Jp + c1 is final for this row */
               QP_SCHED_BARRIER();
               q[u] = PSQ ? U.Lsq[cur][cpre][lrow] : rowp[(size_t)cpre * cstride]; /* refill AFTER the slot's register is free: no queue rotation on the back edge */
