@@ -1112,6 +1112,9 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
 #ifndef QP_RECUR_DPP
 #define QP_RECUR_DPP 1
 #endif
+#ifndef QP_AQD
+#define QP_AQD 4 /* columns in flight (entry of the staged square + its pairs) in the panel wave's "table s-1 on the rows of block s" loop */
+#endif
 #ifndef QP_OWN_A
 #define QP_OWN_A 1 /* staged square (QP_USQ): the entries L(rows of block s, columns of block s-1) are finished and written to HBM by the OWNERS of
                       those rows, which apply table s-1 to them like to every other row below; the panel wave applies the same table to its LDS
@@ -1447,7 +1450,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
            * deeper queue (one row per lane: registers to spare, and this wave is the critical path).
            * The entries of L come from the square the owners staged in LDS (QP_USQ), else from HBM. */
           constexpr bool PSQ = QP_USQ;
-          constexpr int QD = PSQ ? 4 : 8;
+          constexpr int QD = PSQ ? QP_AQD : 8;
           qp_gdouble *rowp = (lane < jb) ? (L + (size_t)Jp * ld + J + lane) : (dummy + lane);
           const size_t cstride = (lane < jb) ? (size_t)ld : 0;
           const int lrow = lane & (NB - 1);
