@@ -139,7 +139,8 @@ int  qpg_ctx_set_option(qpg_ctx *ctx, const char *name, qpg_int value); /* "lds_
 int  qpg_batch_create(qpg_ctx *ctx, qpg_int B, qpg_int n, qpg_int m, qpg_int nnzA_max, qpg_int nnzQ_max,
                       const QPGSettings *settings, qpg_batch **out);
 /* CSC, 64-bit indices as in cholmod_sparse; Q symmetric, only entries with row >= col are read
- * (stype = -1, B6).  Data is copied. */
+ * (stype = -1, B6).  Data is copied -- converted straight into the batch's host slab (huge pages, laid out as it is uploaded);
+ * qpg_batch_create also starts the allocation of the batch's device memory on a thread of its own, qpg_batch_setup joins it. */
 int  qpg_batch_set_problem(qpg_batch *bt, qpg_int idx, const qpg_int *Qp, const qpg_int *Qi, const qpg_float *Qx,
                            const qpg_int *Ap, const qpg_int *Ai, const qpg_float *Ax, const qpg_float *q,
                            qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
@@ -151,12 +152,12 @@ int  qpg_batch_set_problem_sized(qpg_batch *bt, qpg_int idx, qpg_int n, qpg_int 
                                  const qpg_float *q, qpg_float c, const qpg_float *bmin, const qpg_float *bmax);
 /* qpg_batch_set_problem_sized for members first .. first + count - 1 in ONE call (entry k of every array = member first + k; n / m
  * NULL: every member has the batch's dimensions; c NULL: zero constants): the per-QP host work of qpalm_setup -- deep copies,
- * sorted CSC, the A' pattern (src/qpalm.c:128-144, iteration.c:81) -- runs on host threads (QPALM_HOST_THREADS; default: at most 12).  No reference counterpart (the reference sets up one QP per call). */
+ * sorted CSC, the A' pattern (src/qpalm.c:128-144, iteration.c:81) -- runs on host threads (QPALM_HOST_THREADS; default: at most 24).  No reference counterpart (the reference sets up one QP per call). */
 int  qpg_batch_set_problems(qpg_batch *bt, qpg_int first, qpg_int count, const qpg_int *n, const qpg_int *m,
                             const qpg_int *const *Qp, const qpg_int *const *Qi, const qpg_float *const *Qx,
                             const qpg_int *const *Ap, const qpg_int *const *Ai, const qpg_float *const *Ax,
                             const qpg_float *const *q, const qpg_float *c, const qpg_float *const *bmin, const qpg_float *const *bmax);
-int  qpg_batch_setup(qpg_batch *bt);                               /* upload (threads pack, DMA from page-locked staging) + Ruiz scaling on device */
+int  qpg_batch_setup(qpg_batch *bt);                               /* upload (one DMA per array from the host slab) + Ruiz scaling on device */
 int  qpg_batch_warm_start(qpg_batch *bt, const qpg_float *x, const qpg_float *y); /* [B][n], [B][m] or NULL */
 int  qpg_batch_warm_start_last(qpg_batch *bt);                     /* qpalm_warm_start(work, last x, last y) of every QP, from HBM (no host copy) */
 int  qpg_batch_solve(qpg_batch *bt);                               /* run every QP to termination */

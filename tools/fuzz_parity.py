@@ -1,5 +1,6 @@
-"""Randomised parity fuzzing (cases: tests/fuzz_cases.py), the engine against the oracle: status and iteration counts exact, x and
-y to 1e-8.  TEST TOOL (uses oracle/): python tools/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi] [key=value ...]
+"""Randomised parity fuzzing (cases: tests/fuzz_cases.py), the engine against the oracle, judged by the rule of tests/test_fuzz_seeds.py
+(judge_case: status and iteration count exact, x and y to 1e-8 -- y to 1e-5 with sigma_init = 1e3 -- unless the oracle's own outcome
+depends on its floating-point contraction, then status among the variants' and objectives to 10 x eps).  TEST TOOL (uses oracle/): python tools/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi] [key=value ...]
 (key=value pairs force settings, e.g. factorization_method=0 sigma_init=1e3)."""
 import os
 import sys
@@ -8,7 +9,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from qpalm_amd.solver import Context  # noqa: E402
-from tests.fuzz_cases import cases, run_case  # noqa: E402
+from tests.fuzz_cases import cases, judge_case, run_case  # noqa: E402
 
 pos = [a for a in sys.argv[1:] if "=" not in a]
 force = {}
@@ -21,24 +22,20 @@ ctx = Context(0, lib_path=os.path.join(ROOT, 'tests', 'emu', 'libqpalm_gfx950_em
 seed = int(pos[0]) if len(pos) > 0 else 0
 N = int(pos[1]) if len(pos) > 1 else 100
 NLO, NHI = (int(pos[3]), int(pos[4])) if len(pos) > 4 else (2, 70)   # range of n (m up to 1.7 n)
-bad = 0    # status or iteration count differs (or an exception)
-soft = 0   # same status and iterations, x or y beyond 1e-8
+bad = 0    # fails the rule (or an exception)
+soft = 0   # passes as a rounding-decided case
 t0 = time.time()
 for it, p, st, warm, meta in cases(seed, N, NLO, NHI, force or None):
     try:
         r = run_case(ctx, p, st, warm)
-        hard_ok = r["status"][0] == r["status"][1] and r["iter"][0] == r["iter"][1]
-        ok = hard_ok
-        if ok and r["status"][1] in (1, 2):
-            ok = r["dx"] <= 1e-8 and r["dy"] <= 1e-8
-        if not ok:
-            if hard_ok:
-                soft += 1
-            else:
-                bad += 1
-            print("MISMATCH" if not hard_ok else "SOFT", "seed", seed, "case", it, meta, st, "status", r["status"], "iter", r["iter"], "x", r["dx"], "y", r["dy"])
+        ok, why, rounding = judge_case(r, p, st, warm, 1e-5 if st["sigma_init"] >= 1e3 else 1e-8, ctx)
+        if not ok or rounding:
+            bad += 0 if ok else 1
+            soft += 1 if ok else 0
+            print("FAIL" if not ok else "ROUNDING-DECIDED", "seed", seed, "case", it, meta, {k: st[k] for k in ("factorization_method", "sigma_init", "scaling", "proximal")},
+                  "status", r["status"], "iter", r["iter"], "x", r["dx"], "y", r["dy"], "|", why)
             sys.stdout.flush()
     except Exception as e:
         bad += 1
         print("EXC", it, meta, st, repr(e)[:300])
-print("done seed", seed, "cases", N, "status/iteration mismatches", bad, "x/y beyond 1e-8", soft, "time", round(time.time() - t0, 1))
+print("done seed", seed, "cases", N, "n", (NLO, NHI), "forced", force, "FAIL", bad, "rounding-decided", soft, "time", round(time.time() - t0, 1))
