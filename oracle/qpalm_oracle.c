@@ -878,8 +878,23 @@ void oq_ldlupdate_sigma_changed(oq_workspace *w) { /* solver_interface.c:443-503
   }
   sp_scale_col(&w->At_sqrt_sigma, w->At_scale);
   updown_columns(w, sigma_changed, w->nb_sigma_changed, 1);
-  for (oq_int k = 0; k < w->m; k++) At_scalex[k] = 1.0 / At_scalex[k];
+  oq_int zeroed = 0;
+  for (oq_int k = 0; k < w->m; k++) { if (At_scalex[k] == 0.0) zeroed++; At_scalex[k] = 1.0 / At_scalex[k]; }
   sp_scale_col(&w->At_sqrt_sigma, w->At_scale);
+  if (zeroed) {
+    /* NOT in the reference: a sigma that grew by one unit in the last place has sqrt(mult_factor) == 1, its update vector
+     * sqrt(1 - 1/1) A_k is exactly zero (a no-op update) and the reference's CHOLMOD branch then scales the zeroed column back by
+     * 1/0: 0 * inf = NaN in At_sqrt_sigma (solver_interface.c:498-502; the LADEL branch never scales At).  There is no reference
+     * behaviour to restate on such a case; the column is rebuilt from A' and sqrt(sigma), as the engine does (qpalm_iter.h:
+     * dev_update_sigma_post).  Found by the engine's fresh-seed fuzz campaign of round 4 (seed 204 case 155). */
+    oq_sparse T;
+    memset(&T, 0, sizeof T);
+    sp_transpose(&w->A, &T);
+    for (oq_int k = 0; k < w->m; k++)
+      if (isinf(At_scalex[k]))
+        for (oq_int e = T.p[k]; e < T.p[k + 1]; e++) w->At_sqrt_sigma.x[e] = T.x[e] * w->sqrt_sigma[k];
+    sp_free(&T);
+  }
 }
 
 void oq_ldlsolveLD_neg_dphi(oq_workspace *w) { /* solver_interface.c:505-519 */

@@ -358,9 +358,17 @@ QPP int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
 QPP void dev_update_sigma_post(const QpArrays &a, IterShared &I, int nchg) {
   const int m = a.m, tid = threadIdx.x;
   for (int k = tid; k < m; k += QP_T) {
-    const double s = 1.0 / a.At_scale()[k];
+    const double s0 = a.At_scale()[k];
+    const double s = 1.0 / s0;
     a.At_scale()[k] = s;
-    if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s;
+    if (s0 == 0.0) {
+      /* sigma_k grew by one unit in the last place: sqrt(mult_factor) rounds to 1, the row's update vector sqrt(1 - 1/1) A_k is
+       * exactly zero (a no-op sweep, as it should be) -- and scaling the zeroed row back by 1/0 gives 0 * inf = NaN in the
+       * reference's CHOLMOD branch (solver_interface.c:492-502; its LADEL branch never scales At).  The row is rebuilt from A'
+       * instead (found by the fresh-seed fuzz campaign of round 4, seed 204 case 155; the oracle restates the same repair). */
+      const double ssig = a.sqrt_sigma()[k];
+      for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] = a.Atx()[e] * ssig;
+    } else if (s != 1.0) for (int e = a.Atp()[k]; e < a.Atp()[k + 1]; e++) a.Atss()[e] *= s;
   }
   if (tid == 0) { I.s.n_rank1 += nchg; }
   __syncthreads();

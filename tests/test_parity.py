@@ -395,6 +395,10 @@ def test_boundary_ldlupdate_sigma_changed(ctx):
     changed = np.sort(rng.choice(np.where(act == 1)[0], size=19, replace=False))
     scale = np.ones(m)
     scale[changed] = np.sqrt(1.0 + 99.0 * rng.random(19))
+    # ... one of them a sigma that grew by one unit in the last place: sqrt(mult_factor) rounds to 1.0, the row's update vector is exactly
+    # zero and the reference's CHOLMOD branch scales the zeroed row back by 1/0 (NaN); engine and oracle rebuild the row from A'
+    # (fresh-seed fuzz campaign of round 4, seed 204 case 155)
+    scale[changed[7]] = 1.0
     o2.vec("At_scale", copy=False)[:] = scale
     bt.set_vec("At_scale", scale)
     pe = L.oq_get_ivec(o2.w, b"enter", C.byref(ln))
@@ -408,8 +412,11 @@ def test_boundary_ldlupdate_sigma_changed(ctx):
     Lo, Do = o2.factor()
     Lg, Dg = bt.factor()
     assert rel(Dg, Do) <= 1e-10 and np.max(np.abs(np.tril(Lg, -1) - np.tril(Lo, -1))) <= 1e-9
-    assert np.array_equal(bt.vec("At_scale"), o2.vec("At_scale"))           # 1 / sqrt(1 - 1/s^2) on the changed rows
-    assert rel(bt.named_vec("At_sqrt_sigma", int(p.Ap[-1])), Atss0) <= 1e-15  # scaled by s and back by 1/s
+    assert np.array_equal(bt.vec("At_scale"), o2.vec("At_scale"))           # 1 / sqrt(1 - 1/s^2) on the changed rows (inf on the one-ulp row)
+    assert np.isinf(bt.vec("At_scale")[changed[7]])
+    Atss1 = bt.named_vec("At_sqrt_sigma", int(p.Ap[-1]))
+    assert np.all(np.isfinite(Atss1)) and rel(Atss1, Atss0) <= 1e-15          # scaled by s and back by 1/s; the one-ulp row rebuilt
+    assert np.all(np.isfinite(Lg)) and np.all(np.isfinite(Dg))
     # property: D grew (a positive semidefinite term was added)
     bt.op("ldlcholQAtsigmaA")
     assert np.all(Dg >= bt.factor()[1] * (1 - 1e-12))

@@ -1,5 +1,5 @@
 """Randomised parity fuzzing (cases: tests/fuzz_cases.py), the engine against the oracle, judged by the rule of tests/test_fuzz_seeds.py
-(judge_case: status and iteration count exact, x and y to 1e-8 -- y to 1e-5 with sigma_init = 1e3 -- unless the oracle's own outcome
+(judge_case: status and iteration count exact, x to 1e-8, y to max(1e-8, 100 sigma dx) -- unless the oracle's own outcome
 depends on its floating-point contraction, then status among the variants' and objectives to 10 x eps).  TEST TOOL (uses oracle/): python tools/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi] [key=value ...]
 (key=value pairs force settings, e.g. factorization_method=0 sigma_init=1e3)."""
 import os
@@ -28,7 +28,7 @@ t0 = time.time()
 for it, p, st, warm, meta in cases(seed, N, NLO, NHI, force or None):
     try:
         r = run_case(ctx, p, st, warm)
-        ok, why, rounding = judge_case(r, p, st, warm, 1e-5 if st["sigma_init"] >= 1e3 else 1e-8, ctx)
+        ok, why, rounding = judge_case(r, p, st, warm, 1e-8, ctx)
         if not ok or rounding:
             bad += 0 if ok else 1
             soft += 1 if ok else 0
