@@ -34,4 +34,5 @@ timeout 300 python tools/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_p
 timeout 300 python tools/setup_timing.py 8192 > $OUT/setup_timing.txt 2>&1
 timeout 600 python tools/coop_timing.py 512 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
 timeout 300 tools/sload_coherence_test > $OUT/sload_coherence.txt 2>&1
+timeout 200 tools/host_alloc_probe > $OUT/host_alloc_probe.txt 2>&1
 ls -la $OUT
