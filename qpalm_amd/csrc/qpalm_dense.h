@@ -1084,7 +1084,7 @@ template <int R> QPD double qp_row_bcast(double v) { /* ONE v_mov_b64_dpp: row_n
 /* ranks r = R0 .. R1-1 of one rank group applied to a row: w_{OFF+r} += c0_r l, l += c1_r w_{OFF+r}, the pair (c0_r, c1_r) living in
  * lane r of every 16-lane row */
 #ifdef QPALM_EMU
-template <int K, int OFF, int R0, int R1>
+template <int K, int OFF, int R0, int R1, bool FIRST = true>
 QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) { /* same values, one fiber round instead of 2 (R1 - R0) */
   const int lane = threadIdx.x & 63;
   emu_publish2(cw0, cw1);
@@ -1096,13 +1096,37 @@ QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K
   emu_wave_sync();
 }
 #else
-template <int K, int OFF, int R0, int R1>
+#ifndef QP_FMAC_DPP
+#define QP_FMAC_DPP 1 /* the broadcast folded into the FMA: v_fmac_f64_dpp (VOP2 + DPP row_newbcast, gfx90a+) -- two instructions per rank instead of
+                         four.  The compiler does not form it from v_mov_b64_dpp + v_fmac_f64 by itself (ROCm 7.2), hence the inline assembly. */
+#endif
+/* Eight ranks in ONE assembly statement: w_i <- fma(pair_x of lane R0 + i, l, w_i); l <- fma(pair_y of lane R0 + i, w_i, l), i = 0..7.
+ * (One statement per instruction would cost an s_nop between any two of them: the compiler's hazard recogniser assumes the worst
+ * of inline assembly on gfx950 -- dst_sel / cvt-scale forwarding -- and that takes back half of what the fused form saves.)
+ * NOP: a DPP operand must not have been written by one of the two preceding VALU instructions; the recogniser does not look into
+ * the statement, so pairs that come straight out of VALU instructions (the recurrence) pay one s_nop, pairs read from LDS do not. */
+#define QP_FD_STEP(i, n) "v_fmac_f64_dpp %" #i ", %9, %8 row_newbcast:%" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                         "v_fmac_f64_dpp %8, %10, %" #i " row_newbcast:%" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define QP_FD_EIGHT QP_FD_STEP(0, 11) QP_FD_STEP(1, 12) QP_FD_STEP(2, 13) QP_FD_STEP(3, 14) QP_FD_STEP(4, 15) QP_FD_STEP(5, 16) QP_FD_STEP(6, 17) QP_FD_STEP(7, 18)
+template <int R0, bool NOP> QPD void qp_fmac_bcast8(double *w, double &l, const double cw0, const double cw1) {
+  if constexpr (NOP)
+    asm("s_nop 1\n\t" QP_FD_EIGHT
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(l)
+        : "v"(cw0), "v"(cw1), "n"(R0), "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 5), "n"(R0 + 6), "n"(R0 + 7));
+  else
+    asm(QP_FD_EIGHT
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(l)
+        : "v"(cw0), "v"(cw1), "n"(R0), "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 5), "n"(R0 + 6), "n"(R0 + 7));
+}
+template <int K, int OFF, int R0, int R1, bool FIRST = true>
 QPD void qp_apply_ranks_dpp(const double cw0, const double cw1, double (&wrow)[K], double &l) {
-  if constexpr (R0 < R1 && OFF + R0 < K) {
+  if constexpr (QP_FMAC_DPP && R1 - R0 == 8 && OFF + R1 <= K) {
+    qp_fmac_bcast8<R0, FIRST>(&wrow[OFF + R0], l, cw0, cw1);
+  } else if constexpr (R0 < R1 && OFF + R0 < K) {
     const double c0 = qp_row_bcast<R0>(cw0), c1 = qp_row_bcast<R0>(cw1);
     wrow[OFF + R0] = QP_FMA(c0, l, wrow[OFF + R0]);
     l = QP_FMA(c1, wrow[OFF + R0], l);
-    qp_apply_ranks_dpp<K, OFF, R0 + 1, R1>(cw0, cw1, wrow, l);
+    qp_apply_ranks_dpp<K, OFF, R0 + 1, R1, false>(cw0, cw1, wrow, l);
   }
 }
 #endif
@@ -1274,11 +1298,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             for (int g = 0; g < G; g++) cf[g] = tabO[c1 * K + 16 * g];
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) {
-              qp_apply_ranks_dpp<K, 0, 0, 8>(cf[0].x, cf[0].y, w[rr], l[rr]);
-              if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16>(cf[0].x, cf[0].y, w[rr], l[rr]);
+              qp_apply_ranks_dpp<K, 0, 0, 8, false>(cf[0].x, cf[0].y, w[rr], l[rr]);
+              if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16, false>(cf[0].x, cf[0].y, w[rr], l[rr]);
               if constexpr (G > 1) {
-                if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8>(cf[G - 1].x, cf[G - 1].y, w[rr], l[rr]);
-                if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16>(cf[G - 1].x, cf[G - 1].y, w[rr], l[rr]);
+                if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8, false>(cf[G - 1].x, cf[G - 1].y, w[rr], l[rr]);
+                if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16, false>(cf[G - 1].x, cf[G - 1].y, w[rr], l[rr]);
               }
             }
           } else {
@@ -1481,11 +1505,11 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
               double l = q[u];
               const int cpre = (c1 + QD < NB) ? c1 + QD : NB - 1;
               if (QP_PANEL_A_DPP) {
-                qp_apply_ranks_dpp<K, 0, 0, 8>(cfq[u][0].x, cfq[u][0].y, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
-                if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16>(cfq[u][0].x, cfq[u][0].y, wrow, l);
+                qp_apply_ranks_dpp<K, 0, 0, 8, false>(cfq[u][0].x, cfq[u][0].y, wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
+                if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16, false>(cfq[u][0].x, cfq[u][0].y, wrow, l);
                 if constexpr (G > 1) {
-                  if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8>(cfq[u][G - 1].x, cfq[u][G - 1].y, wrow, l);
-                  if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16>(cfq[u][G - 1].x, cfq[u][G - 1].y, wrow, l);
+                  if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8, false>(cfq[u][G - 1].x, cfq[u][G - 1].y, wrow, l);
+                  if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16, false>(cfq[u][G - 1].x, cfq[u][G - 1].y, wrow, l);
                 }
               } else {
 #pragma unroll
@@ -1587,10 +1611,10 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           if (QP_RECUR_DPP) {
             double l = lcur;
             qp_apply_ranks_dpp<K, 0, 0, 8>(nwv[0], ngam[0], wrow, l); /* (ranks >= kk carry zero pairs: exact no-ops) */
-            if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16>(nwv[0], ngam[0], wrow, l);
+            if (KG > 8 && kk > 8) qp_apply_ranks_dpp<K, 0, 8, 16, false>(nwv[0], ngam[0], wrow, l);
             if constexpr (G > 1) {
               if (kk > 16) qp_apply_ranks_dpp<K, 16, 0, 8>(nwv[1], ngam[1], wrow, l);
-              if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16>(nwv[1], ngam[1], wrow, l);
+              if (kk > 24) qp_apply_ranks_dpp<K, 16, 8, 16, false>(nwv[1], ngam[1], wrow, l);
             }
             if (ln > c1 && ln < jb) U.Ld[cur][ln][c1] = l;
             if (QP_PANEL_TIMING == 2) { double ll = l; QP_OPAQUE_V(ll); const long long t = QP_CLOCK(); if (lane == 0) tdbg[11] += t - tc0; }
