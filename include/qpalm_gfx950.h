@@ -131,8 +131,19 @@ int  qpg_validate_settings(const QPGSettings *s);       /* 1 = valid, src/valida
 
 int  qpg_ctx_create(int device, qpg_ctx **out);
 void qpg_ctx_destroy(qpg_ctx *ctx);
-int  qpg_ctx_set_option(qpg_ctx *ctx, const char *name, qpg_int value); /* "lds_bytes", "max_slots",
-                                                                           "update_rank_threshold" */
+/* Engine options (no reference counterpart; they change speed or placement, never what is computed):
+ *   "max_slots"             resident factor panels = workgroups in flight (default 512)
+ *   "lds_bytes"             dynamic LDS per 512-thread workgroup
+ *   "update_rank_threshold" -1 = the reference's refactorise-or-update rule (newton.c:98-101), k >= 0: refactorise beyond k changed rows
+ *   "small_workgroups"      1 = factors of at most 256 rows run on the 256-thread instance of the kernels
+ *   "narrow_rows"           1 = quarter-wavefront Schur assembly for short rows of A
+ *   "ld_align"              leading dimension of the factor panels in doubles (16 = every column on a 128-byte line)
+ *   "sweep_ranks"           16 (default) or 32 ranks per update sweep (32: the multi-pass sweep, bit-identical factors, slower)
+ *   "kkt_compact"           1 = FACTORIZE_KKT factorises the variables + ACTIVE constraints only and spreads the factor out on demand
+ *   "place_panel_wave"      0 / 1 / 2: SIMD placement of the sweeps' panel wavefronts (0 = the hardware's own)
+ *   "coop", "coop_workgroups", "coop_updates", "coop_rank_threshold"   one large QP on many workgroups
+ * Environment: QPALM_HOST_THREADS = host threads of qpg_batch_set_problems (default: hardware threads, at most 24). */
+int  qpg_ctx_set_option(qpg_ctx *ctx, const char *name, qpg_int value);
 
 /* A batch = B QPs of dimensions up to (n, m) (equal for all members with qpg_batch_set_problem, smaller ones through
  * qpg_batch_set_problem_sized).  nnzA_max / nnzQ_max bound the entries of any member. */
