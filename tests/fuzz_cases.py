@@ -8,7 +8,8 @@ from qpalm_amd.problems import random_qp
 
 
 def cases(seed, count, n_lo=2, n_hi=70, force=None):
-    """force: dict of settings that overrides the drawn ones (the draws are made all the same, so the stream stays aligned)"""
+    """force: dict of settings that overrides the drawn ones (the draws are made all the same, so the stream stays aligned);
+    the pseudo-setting q_shift makes the Hessian indefinite (use with nonconvex=1)"""
     rng = np.random.default_rng(int(seed))
     for it in range(count):
         n = int(rng.integers(n_lo, n_hi))
@@ -34,7 +35,14 @@ def cases(seed, count, n_lo=2, n_hi=70, force=None):
         if rng.random() < 0.3:
             warm = (rng.standard_normal(n), rng.standard_normal(m))
         if force:
-            st.update(force)
+            st.update({k: v for k, v in force.items() if k != "q_shift"})
+            if force.get("q_shift"):
+                # indefinite Hessian for the nonconvex front-end: the diagonal of Q lowered by q_shift x its mean (every column of a
+                # random_qp Hessian stores its diagonal entry first)
+                Qp, Qi = np.asarray(p.Qp), np.asarray(p.Qi)
+                dpos = np.array([k for j in range(n) for k in range(int(Qp[j]), int(Qp[j + 1])) if int(Qi[k]) == j], dtype=np.int64)
+                if dpos.size:
+                    p.Qx[dpos] -= float(force["q_shift"]) * float(np.mean(np.abs(p.Qx[dpos])))
         yield it, p, st, warm, dict(n=n, m=m, dA=dA, dM=dM, mode=mode)
 
 
