@@ -68,12 +68,14 @@
 #define QPNI __device__ inline
 typedef double qp_gdouble;
 typedef int qp_gint;
+typedef char qp_gchar;
 #define QP_LDS_ARG(T, p) ((T *)(p))
 #define QP_LDS_AS
 #else
 #define QPNI __device__ __noinline__
 typedef double __attribute__((address_space(1))) qp_gdouble;
 typedef int __attribute__((address_space(1))) qp_gint;
+typedef char __attribute__((address_space(1))) qp_gchar;
 #define QP_LDS_AS __attribute__((address_space(3)))
 /* the LDS block handed to a real function: typed as LDS, its (wave-uniform) offset back in an SGPR and
  * known to be 16-byte aligned, so that accesses are ds_*_b128 with scalar base */
@@ -93,6 +95,7 @@ typedef emu_double4 qp_double4;
 #define QP_SQRT(x) std::sqrt(x)
 #define QP_CLOCK() ((long long)wall_clock64())
 #define QP_UNIFORM(x) (x)
+#define QP_UNIFORM_PTR(p) (p)
 #define QP_OPAQUE(x) do { } while (0)
 #define QP_OPAQUE_V(x) do { } while (0)
 #define QP_FRESH_LANE(lane) (lane)
@@ -119,6 +122,12 @@ static __device__ __forceinline__ char *qp_dyn_lds_opaque_() {
 #define QP_SQRT(x) sqrt(x)
 #define QP_CLOCK() ((long long)wall_clock64())
 #define QP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x) /* value is wave-uniform: keep it in an SGPR */
+template <class P> static __device__ __forceinline__ P qp_uniform_ptr_(P p) { /* a wave-uniform pointer (function arguments arrive in VGPRs) back in an SGPR pair */
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (P)(((unsigned long long)hi << 32) | lo);
+}
+#define QP_UNIFORM_PTR(p) qp_uniform_ptr_(p)
 /* stops LICM/CSE from keeping ~100 per-array addresses live across the whole iteration loop */
 /* (readfirstlane first: after a branch the compiler could not prove uniform the value may sit in a VGPR phi, and a
  * plain "+s" constraint is then an illegal VGPR-to-SGPR copy; on an SGPR value the readfirstlane folds away) */
@@ -276,9 +285,9 @@ QPD void block_compact2(QpShared &S, int count, F0 f0, F1 f1, int *out0, int *ou
 #ifndef QP_SPMV_ROWS
 #define QP_SPMV_ROWS 4 /* rows in flight per lane group; 8 spills under the 128-VGPR cap (measured slower) */
 #endif
-template <int G, class Post>
+template <int G, class XP, class Post>
 QPD void spmv_rows(int nrows, const int *__restrict__ ptr, const int *__restrict__ idx,
-                   const double *__restrict__ val, const double *x, Post post) {
+                   const double *__restrict__ val, XP x, Post post) { /* XP: const double * in HBM, or the vector staged in LDS (spmv_stage_x) */
   /* Every dependent global load costs 0.5-1.5 us here, and a row is a chain of three (pointer ->
    * index/value -> x[index]).  So each group of G lanes walks U rows at once with branch-free,
    * clamped loads: the U chains are in flight together.  Per row the arithmetic is unchanged: lane
@@ -323,6 +332,20 @@ QPD void spmv_rows(int nrows, const int *__restrict__ ptr, const int *__restrict
       if (r < nrows && sub == 0) post(r, a);
     }
   }
+}
+
+/* The gathered vector of an SpMV staged in LDS: the third of a row's three dependent round trips (pointer -> index / value -> x[index])
+ * becomes an LDS read.  Returns nullptr when the vector does not fit the dynamic LDS block (the caller then gathers from HBM).
+ * The caller synchronises before the SpMV and before the block is used for anything else.  Same values, same arithmetic. */
+typedef const double QP_LDS_AS *qp_lds_cdouble;
+#ifndef QP_SPMV_LDS
+#define QP_SPMV_LDS 1 /* 0: gather from HBM as in rounds 1-4 (A/B) */
+#endif
+QPD qp_lds_cdouble spmv_stage_x(const double *x, int nx, char *lds, int lds_bytes) {
+  if (!QP_SPMV_LDS || (size_t)nx * sizeof(double) > (size_t)lds_bytes) return nullptr;
+  double QP_LDS_AS *xs = (double QP_LDS_AS *)lds;
+  for (int i = threadIdx.x; i < nx; i += QP_T) xs[i] = x[i];
+  return xs;
 }
 
 /* per-QP pointer helpers */

@@ -457,8 +457,16 @@ QPPH double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, 
   const int prox = qp_prox(st, I.s);
   __syncthreads();
   long long tl0 = QP_CLOCK();
-  spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), a.d(), [&](int r, double s) { a.Qd()[r] = prox ? (s + ginv * a.d()[r]) : s; });
-  spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), a.d(), [&](int r, double s) { a.Ad()[r] = s; });
+  /* Qd = Q d (+ d / gamma), Ad = A d: d is gathered from LDS (8 n bytes of the block the sort uses afterwards) */
+  const qp_lds_cdouble ds = spmv_stage_x(a.d(), n, lds, V.lds_bytes);
+  __syncthreads();
+  if (QP_UNIFORM((int)(ds != nullptr))) {
+    spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), ds, [&](int r, double s) { a.Qd()[r] = prox ? (s + ginv * ds[r]) : s; });
+    spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), ds, [&](int r, double s) { a.Ad()[r] = s; });
+  } else {
+    spmv_rows<8>(n, a.Qfp(), a.Qfi(), a.Qfx(), (const double *)a.d(), [&](int r, double s) { a.Qd()[r] = prox ? (s + ginv * a.d()[r]) : s; });
+    spmv_rows<8>(m, a.Atp(), a.Ati(), a.Atx(), (const double *)a.d(), [&](int r, double s) { a.Ad()[r] = s; });
+  }
   __syncthreads();
   if (tid == 0) { const long long t = QP_CLOCK(); I.s.ticks_dbg[13] += t - tl0; tl0 = t; } /* 13: line-search SpMVs */
   double vm[1] = {0.0}, vs[4] = {0.0, 0.0, 0.0, 0.0};
@@ -697,6 +705,10 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     for (int k = 0; k < 8; k++) vm[k] = 0.0;
     for (int k = 0; k < 4; k++) vs[k] = 0.0;
     double viol = 0.0;
+    /* yh also goes into the dynamic LDS block (free in this phase) when it fits: A' yh then gathers it from there -- the third of a
+     * column's three dependent round trips (pointer -> index / value -> yh[index]) becomes an LDS read */
+    const bool ys_lds = QP_UNIFORM((int)(QP_SPMV_LDS && (size_t)m * sizeof(double) <= (size_t)V.lds_bytes)) != 0;
+    double QP_LDS_AS *ys = (double QP_LDS_AS *)lds;
     for (int i = tid; i < m; i += QP_T) {
       const double yv = a.y()[i], ax = a.Axv()[i];
       double t = yv * a.sigma_inv()[i];
@@ -706,6 +718,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       t = pr * a.sigma()[i];
       const double yhv = yv + 1 * t;
       a.Axys()[i] = axys; a.z()[i] = zz; a.pri_res()[i] = pr; a.yh()[i] = yhv;
+      if (ys_lds) ys[i] = yhv;
       const double dy = yhv + (-1) * yv;
       a.delta_y()[i] = dy;
       if (scal) {
@@ -731,7 +744,8 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     __syncthreads();
     QP_OPAQUE(a.b);
     /* ---- Atyh = A' yh (iteration.c:45) ------------------------------------------------------- */
-    spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), a.yh(), [&](int r, double s) { a.Atyh()[r] = s; });
+    if (ys_lds) spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), (qp_lds_cdouble)ys, [&](int r, double s) { a.Atyh()[r] = s; });
+    else spmv_rows<16>(n, a.Ap(), a.Ai(), a.Ax(), (const double *)a.yh(), [&](int r, double s) { a.Atyh()[r] = s; });
     __syncthreads();
     /* ---- df, dphi (iteration.c:37-47) + dual residual norms (termination.c:61-129) ---------- */
     gam = I.s.gamma;
