@@ -289,6 +289,32 @@ void oq_dense_ldl_rank1(oq_int n, oq_float *L, oq_int ld, oq_float *D, oq_float 
   oq_float alpha = 1.0;
   oq_int j0 = 0;
   while (j0 < n && w[j0] == 0.0) j0++;
+#ifdef OQ_PIVOT_ENGINE
+  /* TEST VARIANT ONLY (tests/fuzz_cases.py: oracle_variants, "pivot"): the same recurrence in the algebraically equal form the
+   * device code uses (qpalm_amd/csrc/qpalm_dense.h, dense_updown: 1/alpha carried along, d_new = d + s w^2 / alpha, one reciprocal
+   * per pivot instead of three divisions).  Like the -ffp-contract / -Ofast builds it answers one question: is the iteration count
+   * of a case a property of the algorithm, or of how this recurrence is rounded? */
+  {
+    const oq_float sgn = update ? 1.0 : -1.0;
+    oq_float ialpha = 1.0;
+    for (oq_int j = j0; j < n; j++) {
+      const oq_float wj = w[j], dprev = D[j];
+      const oq_float pinc = sgn * wj * wj * ialpha;
+      const oq_float dnew = dprev + pinc;
+      const oq_float rdn = 1.0 / dnew, rdp = 1.0 / dprev;
+      const oq_float gam = -sgn * wj * ialpha * rdn;
+      if (wj != 0.0) { alpha = alpha * dnew * rdp; ialpha = ialpha * dprev * rdn; }
+      D[j] = dnew;
+      oq_float *Lj = L + j * ld;
+      for (oq_int i = j + 1; i < n; i++) {
+        oq_float wi = w[i] - wj * Lj[i];
+        w[i] = wi;
+        Lj[i] -= gam * wi;
+      }
+    }
+    return;
+  }
+#endif
   for (oq_int j = j0; j < n; j++) {
     oq_float wj = w[j];
     oq_float dj = D[j];

@@ -500,7 +500,9 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, char *stage_
 #ifndef QP_NI_FDIAG
 #define QP_NI_FDIAG QPNI
 #endif
-QP_NI_FDIAG void factor_diag_block(char *lds_) {
+QP_NI_FDIAG void factor_diag_block(char *lds_, double *Lout_ = nullptr, int ld_ = 0, int jb_ = 0, double *Dout_ = nullptr) {
+  /* Lout_ (the fused dense_factor): address of the block's first entry L(J0, J0) in the panel -- the finished strict lower triangle and
+   * the pivots also go straight from the registers to HBM (rows < jb_), no second trip through LDS for the write-back */
   FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
   constexpr int NB = QP_FNB;
   const int r = (int)(threadIdx.x & (NB - 1));
@@ -522,6 +524,14 @@ QP_NI_FDIAG void factor_diag_block(char *lds_) {
   if ((threadIdx.x & 63) < NB) { /* (any wavefront may be the one that factorises: the fused dense_factor uses wavefronts 0 and 1) */
 #pragma unroll
     for (int c = 0; c < NB; c++) if (r > c) F.Ld[r][c] = p[c];
+    F.Ld[r][r] = 0.0; /* strict lower triangle = L, everything else zero (the fused dense_factor's chain relies on it) */
+    if (Lout_) {
+      const int ld = QP_UNIFORM(ld_), jb = QP_UNIFORM(jb_);
+      qp_gdouble *Lo = QP_UNIFORM_PTR((qp_gdouble *)Lout_), *Do = QP_UNIFORM_PTR((qp_gdouble *)Dout_);
+#pragma unroll
+      for (int c = 0; c < NB; c++) if (r > c && r < jb) Lo[(size_t)c * ld + r] = p[c];
+      if (r < jb) Do[r] = F.dg[r]; /* written by this lane's own column step above: lane r == c */
+    }
   }
 }
 
@@ -550,6 +560,9 @@ QP_NI_FDIAG void factor_diag_block(char *lds_) {
  * column and ~140 calls with their callee-saved registers: 47 MB read + 22.5 MB written per factorisation at n = 1000 for 4.3
  * compulsory, profiles/r04/final/phase_traffic).
  * ------------------------------------------------------------------------------------------- */
+#ifndef QP_FCHG
+#define QP_FCHG 2
+#endif
 #ifndef QP_FDIAG_PRIO
 #define QP_FDIAG_PRIO 0
 #endif
@@ -709,58 +722,74 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *l
         if (wact) kloop(std::integral_constant<int, 1>()); else kloop(std::integral_constant<int, 0>());
       }
       if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[4] += tq1 - tq0; tq0 = tq1; }
-      /* ---- a diagonal block: accumulators -> LDS, factorised by its wavefront in registers, L and d back to HBM ---------- */
-      auto diag = [&](auto blk) QP_ALWAYS_INLINE {
-        constexpr int BLK = decltype(blk)::value, CT0 = 2 * BLK;
+      /* The in-block phases work on the 2 x 8 entries of ONE 32-column block as plain scalars e[t][i2] (i2 = 4 ct + r: column
+       * 4 i2 + l4 of the block), taken out of the accumulator tuples: element-wise updates of the 8-register MFMA tuples made the
+       * compiler keep (and spill) several versions of them. */
+      /* ---- a diagonal block: entries -> LDS, factorised by its wavefront in registers, L and d straight to HBM ---------- */
+      auto diag = [&](const int BLK, double (&e)[2][8]) QP_ALWAYS_INLINE {
         FactorLds QP_LDS_AS &B = F.B[BLK];
         const int J0 = J + NB * BLK, jb = BLK ? jb2 : jb1;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-          for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int rr = 16 * t + l15, cc = 16 * ct + 4 * r + l4;
-              B.Ld[rr][cc] = (rr >= cc && rr < jb) ? acc[t][CT0 + ct][r] : ((rr == cc) ? 1.0 : 0.0);
-            }
+          for (int i2 = 0; i2 < 8; i2++) {
+            const int rr = 16 * t + l15, cc = 4 * i2 + l4;
+            B.Ld[rr][cc] = (rr >= cc && rr < jb) ? e[t][i2] : ((rr == cc) ? 1.0 : 0.0);
+          }
         QP_WAVE_SYNC();
         if (QP_FDIAG_PRIO) QP_SETPRIO(3); /* the seven other wavefronts of the workgroup wait for this one */
-        if (QP_CALL_BLOCK()) factor_diag_block((char *)&B);
+        if (QP_CALL_BLOCK()) factor_diag_block((char *)&B, (double *)(L + (size_t)J0 * ld + J0), ld, jb, (double *)(Dg + J0));
         if (QP_FDIAG_PRIO) QP_SETPRIO(0);
         QP_WAVE_SYNC();
-        for (int e = lane; e < NB * NB; e += 64) {
-          const int c = e / NB, r = e % NB;
-          if (r > c && r < jb) L[(size_t)(J0 + c) * ld + (J0 + r)] = B.Ld[r][c];
-        }
-        if (lane < jb) Dg[J0 + lane] = B.dg[lane];
       };
-      /* ---- the in-block chain of one 32-column block on the accumulators, then l = u / d and the one store per entry ---- */
-      auto chain = [&](auto blk) QP_ALWAYS_INLINE {
-        constexpr int BLK = decltype(blk)::value, CT0 = 2 * BLK;
+      /* ---- the in-block chain of one 32-column block, then l = u / d and the one store per entry ---- */
+      auto chain = [&](const int BLK, double (&e)[2][8]) QP_ALWAYS_INLINE {
         FactorLds QP_LDS_AS &B = F.B[BLK];
         const int J0 = J + NB * BLK;
+        /* Four columns per step: the columns 4 idx .. 4 idx + 3 are the SAME register in the four lane groups.  Every lane gathers the
+         * four values of its row (ds_bpermute), finishes them itself -- u0 = p0, u1 = p1 - u0 l10, u2 = (p2 - u0 l20) - u1 l21, ... :
+         * per entry the fmas of the column-by-column form, in the same order -- and applies the four to its own and its later columns
+         * (c ascending).  Eight serial steps per block instead of thirty-two: a step costs one LDS round trip (the gather; the entries
+         * of the diagonal block it needs are read next to it), and under the load of a second workgroup's sweep on the same CU that
+         * round trip is ~400 clk (the column-by-column form measured 35 us per pass). */
 #pragma unroll
-        for (int c = 0; c < NB; c++) {
-          const int idx = c >> 2, g = c & 3; /* register (ct, r) = (idx / 4, idx % 4) of lane group g holds column c */
-          double ub[2];
+        for (int idx = 0; idx < 8; idx++) {
+          const int c0 = 4 * idx;
+          double nu[2][4]; /* -u of the four columns, both tiles */
 #pragma unroll
-          for (int t = 0; t < 2; t++) ub[t] = -qp_bperm(acc[t][CT0 + (idx >> 2)][idx & 3], bp0 + 64 * g);
-          if (g < 3) { /* the later columns of the same register: lane groups above g (a select, not a branch: with basic blocks inside the
-                        * chain the compiler sinks the other columns' fmas below them and spills their operands) */
-            const double lv = B.Ld[4 * idx + l4][c];
+          for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) nu[t][g] = -qp_bperm(e[t][idx], bp0 + 64 * g);
+          const double m10 = B.Ld[c0 + 1][c0], m20 = B.Ld[c0 + 2][c0], m21 = B.Ld[c0 + 2][c0 + 1];
+          const double m30 = B.Ld[c0 + 3][c0], m31 = B.Ld[c0 + 3][c0 + 1], m32 = B.Ld[c0 + 3][c0 + 2];
+#pragma unroll
+          for (int t = 0; t < 2; t++) { /* (nu holds -p on entry: u1 = p1 - u0 l10 = fma(-u0, l10, p1)) */
+            double u1 = QP_FMA(nu[t][0], m10, -nu[t][1]);
+            double u2 = QP_FMA(nu[t][0], m20, -nu[t][2]);
+            u2 = QP_FMA(-u1, m21, u2);
+            double u3 = QP_FMA(nu[t][0], m30, -nu[t][3]);
+            u3 = QP_FMA(-u1, m31, u3);
+            u3 = QP_FMA(-u2, m32, u3);
+            nu[t][1] = -u1; nu[t][2] = -u2; nu[t][3] = -u3;
+          }
+          /* i2 == idx: the lane's own column 4 idx + l4 receives the columns before it through the same four fmas -- the diagonal and
+           * the upper triangle of the staged block are zero (factor_diag_block clears the diagonal), so the terms k >= l4 add an exact
+           * zero and what is left is u_{l4}, bit for bit.  No select, no branch in the chain. */
+#pragma unroll
+          for (int i2 = idx; i2 < 8; i2++) {
+            const double lv0 = B.Ld[4 * i2 + l4][c0], lv1 = B.Ld[4 * i2 + l4][c0 + 1], lv2 = B.Ld[4 * i2 + l4][c0 + 2], lv3 = B.Ld[4 * i2 + l4][c0 + 3];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-              const double nv = QP_FMA(ub[t], lv, acc[t][CT0 + (idx >> 2)][idx & 3]);
-              acc[t][CT0 + (idx >> 2)][idx & 3] = (l4 > g) ? nv : acc[t][CT0 + (idx >> 2)][idx & 3];
+              double a = e[t][i2];
+              a = QP_FMA(nu[t][0], lv0, a);
+              a = QP_FMA(nu[t][1], lv1, a);
+              a = QP_FMA(nu[t][2], lv2, a);
+              a = QP_FMA(nu[t][3], lv3, a);
+              e[t][i2] = a;
             }
+            if (((i2 - idx) % QP_FCHG) == QP_FCHG - 1) QP_SCHED_BARRIER(); /* at most QP_FCHG registers' worth of block entries (8 VGPRs each) in flight */
           }
-#pragma unroll
-          for (int i2 = idx + 1; i2 < 8; i2++) {
-            const double lv = B.Ld[4 * i2 + l4][c];
-#pragma unroll
-            for (int t = 0; t < 2; t++) acc[t][CT0 + (i2 >> 2)][i2 & 3] = QP_FMA(ub[t], lv, acc[t][CT0 + (i2 >> 2)][i2 & 3]);
-          }
-          QP_SCHED_BARRIER(); /* one column at a time: left alone the scheduler gathers the operands of several columns first and spills them */
+          QP_SCHED_BARRIER(); /* one step at a time: left alone the scheduler gathers the operands of several steps first and spills them */
         }
         /* l = u / d and the one store of the entry: uniform column base + per-lane byte offset, no masks on a tile inside the matrix */
         const unsigned vs0 = (unsigned)(l4 * ld + row[0]) * 8u;
@@ -770,9 +799,9 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *l
           const int cc = 4 * i2 + l4, col = J0 + cc;
           const double dvv = B.dv[cc];
           qp_gchar *cp = (qp_gchar *)(L + (size_t)(J0 + 4 * i2) * ld);
-          const double lv0 = acc[0][CT0 + (i2 >> 2)][i2 & 3] * dvv, lv1 = acc[1][CT0 + (i2 >> 2)][i2 & 3] * dvv;
-          acc[0][CT0 + (i2 >> 2)][i2 & 3] = lv0;
-          acc[1][CT0 + (i2 >> 2)][i2 & 3] = lv1;
+          const double lv0 = e[0][i2] * dvv, lv1 = e[1][i2] * dvv;
+          e[0][i2] = lv0;
+          e[1][i2] = lv1;
           if (fullst) {
             *(qp_gdouble *)(cp + vs0) = lv0;
             *(qp_gdouble *)(cp + vs0 + 128) = lv1;
@@ -782,13 +811,18 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *l
           }
         }
       };
+      double e1[2][8]; /* the first block's entries */
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i2 = 0; i2 < 8; i2++) e1[t][i2] = acc[t][i2 >> 2][i2 & 3];
       if (first) {
-        if (diag1) diag(std::integral_constant<int, 0>());
+        if (diag1) diag(0, e1);
         __syncthreads();
         if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
       }
       const bool do1 = wact && !diag1;
-      if (do1) chain(std::integral_constant<int, 0>());
+      if (do1) chain(0, e1);
       if (has2) {
         if (first) {
           if (diag2) { /* the square under the first diagonal block as the operand of every wavefront's P4 */
@@ -797,29 +831,34 @@ QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *l
 #pragma unroll
               for (int i2 = 0; i2 < 8; i2++) {
                 const int k = 4 * i2 + l4;
-                F.Sq[k][16 * t + l15] = -(acc[t][i2 >> 2][i2 & 3] * F.B[0].dg[k]);
+                F.Sq[k][16 * t + l15] = -(e1[t][i2] * F.B[0].dg[k]);
               }
           }
           __syncthreads();
         }
-        if (do1) { /* P4 */
+        if (do1) { /* P4: the panel fragment of step h is the lane's own finished entry of column 4 h + l4 */
 #pragma unroll
           for (int h = 0; h < NB / 4; h++) {
             const double pa2 = F.Sq[4 * h + l4][l15], pa3 = F.Sq[4 * h + l4][16 + l15];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-              acc[t][2] = QP_MFMA_F64(pa2, acc[t][h >> 2][h & 3], acc[t][2]);
-              acc[t][3] = QP_MFMA_F64(pa3, acc[t][h >> 2][h & 3], acc[t][3]);
+              acc[t][2] = QP_MFMA_F64(pa2, e1[t][h], acc[t][2]);
+              acc[t][3] = QP_MFMA_F64(pa3, e1[t][h], acc[t][3]);
             }
           }
         }
+        double e2[2][8]; /* the second block's entries */
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int i2 = 0; i2 < 8; i2++) e2[t][i2] = acc[t][2 + (i2 >> 2)][i2 & 3];
         if (first) {
           if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
-          if (diag2) diag(std::integral_constant<int, 1>());
+          if (diag2) diag(1, e2);
           __syncthreads();
           if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
         }
-        if (do1 && !diag2) chain(std::integral_constant<int, 1>());
+        if (do1 && !diag2) chain(1, e2);
       }
       if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
     }
