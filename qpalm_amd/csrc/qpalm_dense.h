@@ -429,7 +429,7 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, char *stage_
       if (kk < QP_FKC) F.As[buf][kk][i] = sv[q];
     }
   };
-  constexpr int NH = QP_FKC / 4, S = (QP_FST < NH) ? QP_FST : NH;
+  constexpr int S = QP_FST, NH = QP_FKC / 4;
   static_assert(NH % S == 0, "QP_FST must divide QP_FKC / 4");
   double rb[S][NTJ];
   auto loadb = [&](const int st, const int k) QP_ALWAYS_INLINE { /* the panel re-read of the left-looking update */
@@ -491,6 +491,48 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, char *stage_
   }
 }
 
+/* Step (3) of dense_factor as its own function: one row per thread, the row's 32 panel entries live
+ * in registers (64 VGPRs), L and 1/D of the diagonal block come as LDS broadcasts. */
+#ifndef QP_NI_FROWS
+#define QP_NI_FROWS QPNI
+#endif
+QP_NI_FROWS void factor_panel_rows(double *L_, char *lds_, const int n_, const int ld_, const int J_, const int jb_) {
+  const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_), J = QP_UNIFORM(J_), jb = QP_UNIFORM(jb_); /* wave-uniform arguments back to SGPRs */
+  qp_gdouble *L = (qp_gdouble *)L_;
+  FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
+  constexpr int NB = QP_FNB;
+  /* FULL = all 32 columns exist (every block but possibly the last): no per-column conditionals */
+  auto rows = [&](auto full) QP_ALWAYS_INLINE {
+    constexpr bool FULL = decltype(full)::value;
+#pragma unroll 1
+    for (int i = J + jb + threadIdx.x; i < n; i += QP_T) {
+      qp_gdouble *base = L + (size_t)J * ld + i;
+      double u[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) u[c] = (FULL || c < jb) ? base[(size_t)c * ld] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (FULL || c < jb) {
+          double v = u[c];
+#pragma unroll
+          for (int c1 = 0; c1 < c; c1++) {
+            v = QP_FMA(-u[c1], F.Ld[c][c1], v);
+            if ((c1 & 7) == 7) QP_SCHED_BARRIER(); /* at most eight LDS operands in registers next to u[32] */
+          }
+          u[c] = v; /* un-normalised l*d */
+        }
+        QP_SCHED_BARRIER();
+      }
+      int ld2 = ld;
+      QP_OPAQUE(ld2); /* store addresses are recomputed: 32 live column pointers would cost 64 VGPRs */
+#pragma unroll
+      for (int c = 0; c < NB; c++)
+        if (FULL || c < jb) base[(size_t)c * ld2] = u[c] * F.dv[c];
+    }
+  };
+  if (jb == NB) rows(std::true_type()); else rows(std::false_type());
+}
+
 /* Step (2) of dense_factor as its own function (own register allocation): the staged 32 x 32 diagonal block (rows
  * beyond the matrix = identity) is factorised by ONE wavefront with the whole block in registers: lane = row (both
  * half-waves hold the same rows), register c = column c.  Per column c: the pivot and the un-normalised column entries
@@ -500,9 +542,7 @@ QP_NI_FGEMM void factor_panel_update(double *L_, const double *Dg_, char *stage_
 #ifndef QP_NI_FDIAG
 #define QP_NI_FDIAG QPNI
 #endif
-QP_NI_FDIAG void factor_diag_block(char *lds_, double *Lout_ = nullptr, int ld_ = 0, int jb_ = 0, double *Dout_ = nullptr) {
-  /* Lout_ (the fused dense_factor): address of the block's first entry L(J0, J0) in the panel -- the finished strict lower triangle and
-   * the pivots also go straight from the registers to HBM (rows < jb_), no second trip through LDS for the write-back */
+QP_NI_FDIAG void factor_diag_block(char *lds_) {
   FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
   constexpr int NB = QP_FNB;
   const int r = (int)(threadIdx.x & (NB - 1));
@@ -519,68 +559,13 @@ QP_NI_FDIAG void factor_diag_block(char *lds_, double *Lout_ = nullptr, int ld_ 
       p[c2] = QP_FMA(-lic, s, p[c2]);       /* meaningful for rows r >= c2; rows above the diagonal are never read */
     }
     p[c] = lic;
-    if (r == c && (threadIdx.x & 63) < NB) { F.dv[c] = 1.0 / dc; F.dg[c] = dc; } /* reciprocal pivot for the panel rows */
+    if (r == c && threadIdx.x < NB) { F.dv[c] = 1.0 / dc; F.dg[c] = dc; } /* reciprocal pivot for the panel rows */
   }
-  if ((threadIdx.x & 63) < NB) { /* (any wavefront may be the one that factorises: the fused dense_factor uses wavefronts 0 and 1) */
+  if (threadIdx.x < NB) {
 #pragma unroll
     for (int c = 0; c < NB; c++) if (r > c) F.Ld[r][c] = p[c];
-    F.Ld[r][r] = 0.0; /* strict lower triangle = L, everything else zero (the fused dense_factor's chain relies on it) */
-    if (Lout_) {
-      const int ld = QP_UNIFORM(ld_), jb = QP_UNIFORM(jb_);
-      qp_gdouble *Lo = QP_UNIFORM_PTR((qp_gdouble *)Lout_), *Do = QP_UNIFORM_PTR((qp_gdouble *)Dout_);
-#pragma unroll
-      for (int c = 0; c < NB; c++) if (r > c && r < jb) Lo[(size_t)c * ld + r] = p[c];
-      if (r < jb) Do[r] = F.dg[r]; /* written by this lane's own column step above: lane r == c */
-    }
   }
 }
-
-/* ---------------------------------------------------------------------------------------------
- * dense_factor, fused form (round 5): every entry of the factor is written ONCE.
- *
- * Left-looking over super-blocks of 64 columns; the rows below (and in) a super-block are taken in passes of 32 rows per
- * wavefront.  Per pass a wavefront
- *   P1  loads its 32 x 64 tile of H into MFMA accumulators (layout of v_mfma_f64_16x16x4: lane (l15, l4) holds row l15 of the
- *       16-row tile t and, of the 16-column tile ct, the columns l4 + 4 r, r = 0..3) and subtracts L(rows, 0:J) D L(J:J+64, 0:J)'
- *       on the matrix cores (block-row operand staged in LDS by all threads, own rows streamed from HBM: the one panel re-read
- *       of the left-looking form);
- *   P3  finishes the first 32 columns IN the accumulators: u_c = p_c - sum_{c1<c} u_c1 l(c, c1), c ascending, one fma per c1 --
- *       right-looking inside the block (after column c is final its value is handed to the three other lane groups of the row
- *       with ds_bpermute and applied to every later column of the lane), which is the same sequence of fmas per entry as the
- *       row-per-thread loop it replaces -- then l = u / d (times the stored reciprocal) and ONE store per entry;
- *   P4  applies those 32 columns to the second 32 (k = J .. J+31 in MFMA steps of four: the panel fragment of step h is the
- *       lane's own accumulator register of the first block, no data movement), operand -L(J+32+i, k) D(k) from LDS;
- *   P5  finishes and stores the second 32 columns like the first.
- * In the first pass of a super-block wavefront 0 owns the rows of the first diagonal block and wavefront 1 those of the second:
- * they put their tiles into LDS, factorise them in registers (factor_diag_block, unchanged) and publish L, d, 1/d and the
- * square's operand between the phases (three more barriers in that pass only).
- * Per entry the arithmetic is exactly the one of the three-function form of rounds 1-4 (and of the coop kernels): k < J' in
- * MFMA groups of four, ascending (J' = the entry's 32-column block), then the in-block chain in plain fmas.  What changed is
- * the traffic: H is read once, L written once, nothing in between goes through HBM (before: three to four passes per block
- * column and ~140 calls with their callee-saved registers: 47 MB read + 22.5 MB written per factorisation at n = 1000 for 4.3
- * compulsory, profiles/r04/final/phase_traffic).
- * ------------------------------------------------------------------------------------------- */
-#ifndef QP_FCHG
-#define QP_FCHG 2
-#endif
-#ifndef QP_FDIAG_PRIO
-#define QP_FDIAG_PRIO 0
-#endif
-#ifndef QP_FFST
-#define QP_FFST 4 /* panel fragments (k steps of four columns) in flight per wavefront in the fused factorisation */
-#endif
-struct FusedFactorLds {
-  FactorLds B[2];                  /* the two diagonal blocks of the super-block: L (strict lower), 1/d, d */
-  double Sq[QP_FNB][QP_FNB + 2];   /* Sq[k][c] = -L(J+32+c, J+k) d(J+k) */
-};
-#ifdef QPALM_EMU
-QPD double qp_bperm(double v, int byte_addr) { return emu_exchange(v, byte_addr >> 2); }
-#else
-QPD double qp_bperm(double v, int byte_addr) { /* the value of lane byte_addr / 4 */
-  const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-#endif
 
 template <int RPT>
 #ifndef QP_NI_FACTOR
@@ -589,279 +574,61 @@ template <int RPT>
 QP_NI_FACTOR void dense_factor(double *L_, double *Dg_, int n_, int ld_, char *lds_, int64_t *tdbg_) {
   const int n = QP_UNIFORM(n_), ld = QP_UNIFORM(ld_); /* wave-uniform arguments back to SGPRs */
   int64_t QP_LDS_AS *tdbg = (int64_t QP_LDS_AS *)tdbg_; /* the timers live in the kernel's static LDS */
-  qp_gdouble *L = QP_UNIFORM_PTR((qp_gdouble *)L_), *Dg = QP_UNIFORM_PTR((qp_gdouble *)Dg_); /* wave-uniform bases in SGPRs */
-  FusedFactorLds QP_LDS_AS &F = *QP_LDS_ARG(FusedFactorLds, lds_);
-  char *stage_ = lds_ + ((sizeof(FusedFactorLds) + 15) & ~(size_t)15);
-  FactorStage QP_LDS_AS &G = *QP_LDS_ARG(FactorStage, stage_);
-  const int tid = threadIdx.x, lane = tid & 63, wid = QP_UNIFORM(tid >> 6);
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int bp0 = l15 * 4; /* ds_bpermute address of this lane's row in lane group 0 */
-  constexpr int NB = QP_FNB, SB = 2 * QP_FNB;
-  constexpr int SE = QP_FKC / QP_NW; /* staged columns per thread and chunk */
-  static_assert(QP_FKC % QP_NW == 0 && SB == 64, "one thread stages one block row of QP_FKC / QP_NW columns");
-  constexpr int NH = QP_FKC / 4, S = (QP_FFST < NH) ? QP_FFST : NH;
-  static_assert(NH % S == 0, "QP_FFST must divide QP_FKC / 4");
+  qp_gdouble *L = (qp_gdouble *)L_, *Dg = (qp_gdouble *)Dg_;
+  FactorLds QP_LDS_AS &F = *QP_LDS_ARG(FactorLds, lds_);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int NB = QP_FNB;
+  __syncthreads();
   long long tq0 = QP_CLOCK();
-  for (int J = 0; J < n; J += SB) {
-    const int jb1 = (n - J < NB) ? (n - J) : NB;
-    const bool has2 = (J + NB < n);
-    const int jb2 = has2 ? ((n - J - NB < NB) ? (n - J - NB) : NB) : 0;
-    const int ntiles = (n - J + 15) / 16;
-    __syncthreads(); /* the columns before J are complete and visible; the LDS blocks of the previous super-block are free */
-    if (tid == 0 && J > 0) {
-      const long long npass = (ntiles + 2 * QP_NW - 1) / (2 * QP_NW);
-      tdbg[QPG_CNT_FACTOR_REREAD] += (long long)(n - J) * J + npass * SB * (long long)J;
-    }
-#pragma unroll 1
-    for (int tb = 0, pass = 0; tb < ntiles; tb += 2 * QP_NW, pass++) {
-      const int tile0 = tb + 2 * wid;
-      const bool wact = (J + 16 * tile0 < n);          /* this wavefront has rows in this pass */
-      int row[2];
-      row[0] = J + 16 * tile0 + l15;
-      row[1] = row[0] + 16;
-      const bool first = (pass == 0);
-      const bool diag1 = first && wid == 0, diag2 = first && wid == 1;
-      /* Every global address below is a wave-uniform 64-bit base (SGPRs) plus a 32-bit per-lane byte offset: under the
-       * 128-register cap the 64-bit per-lane addresses of the straightforward form pushed accumulator tiles into scratch inside
-       * the MFMA loop.  Rows beyond the matrix read in-bounds values of the slot (clamped offsets) and are never stored. */
-      const int rowc = (row[0] < n) ? row[0] : J + l15;
-      const unsigned vrb = (unsigned)(l4 * ld + rowc) * 8u;          /* (column k + l4, row) relative to column k */
-      const unsigned o1 = (row[1] < n) ? 128u : 0u;                   /* the second tile's rows, 16 below */
-      qp_double4 acc[2][4];
-      /* ---- P1: tile of H into the accumulators (one branch-free form: clamped addresses, values selected afterwards).  The loads are
-       * issued behind the first staged chunk's and the first panel fragments' (acc_load), the selects come after the barrier that
-       * publishes the chunk (acc_mask): one latency for all of them ---------------------------------------------------------- */
-      int Jp = J;
-      QP_OPAQUE(Jp); /* the per-entry masks and offsets are recomputed in every pass instead of living (spilled) across the passes of a super-block */
-      auto acc_load = [&]() QP_ALWAYS_INLINE {
-        const qp_gchar *cb = (const qp_gchar *)(L + (size_t)Jp * ld); /* column J */
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int col = Jp + 16 * ct + 4 * r + l4;
-            const unsigned vo = (col < n) ? vrb + (unsigned)((16 * ct + 4 * r) * ld) * 8u : (unsigned)rowc * 8u; /* a column beyond the matrix reads column J */
-            acc[0][ct][r] = *(const qp_gdouble *)(cb + vo);
-            acc[1][ct][r] = *(const qp_gdouble *)(cb + vo + o1);
-          }
-      };
-      auto acc_mask = [&]() QP_ALWAYS_INLINE {
-        if (QP_UNIFORM((int)((16 * tile0 >= SB) && (Jp + 16 * tile0 + 32 <= n) && (Jp + SB <= n))) != 0) return; /* a tile inside the matrix and below the super-block */
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int col = Jp + 16 * ct + 4 * r + l4;
-            acc[0][ct][r] = (col < n && row[0] < n && row[0] >= col) ? acc[0][ct][r] : 0.0;
-            acc[1][ct][r] = (col < n && row[1] < n && row[1] >= col) ? acc[1][ct][r] : 0.0;
-          }
-      };
-      if (J == 0) { acc_load(); acc_mask(); }
-      if (J > 0) {
-        /* staging: thread (wid, lane) handles block row `lane` of the chunk's columns wid, wid + QP_NW, ... */
-        const bool rwok = (J + lane < n);
-        const unsigned vst = (unsigned)(wid * ld + J + (rwok ? lane : 0)) * 8u;
-        double sv[SE];
-        auto stage_load = [&](const int kb) QP_ALWAYS_INLINE {
-          const qp_gchar *sb = (const qp_gchar *)(L + (size_t)kb * ld);
-          const qp_gdouble *db = Dg + kb + wid;
-#pragma unroll
-          for (int q = 0; q < SE; q++) {
-            const double lv = *(const qp_gdouble *)(sb + (size_t)(q * QP_NW) * ld * 8 + vst);
-            sv[q] = rwok ? -(lv * db[q * QP_NW]) : 0.0;
-          }
-        };
-        auto stage_store = [&](const int buf) QP_ALWAYS_INLINE {
-#pragma unroll
-          for (int q = 0; q < SE; q++) G.As[buf][wid + q * QP_NW][lane] = sv[q];
-        };
-        auto kloop = [&](auto actc) QP_ALWAYS_INLINE { /* ACT = 0: a wavefront without rows only stages and keeps the barriers */
-          constexpr bool ACT = decltype(actc)::value != 0;
-          double rb[S][2];
-          auto loadb = [&](const int st, const int k) QP_ALWAYS_INLINE { /* the panel re-read of the left-looking update */
-            if (ACT) {
-              const qp_gchar *kb_ = (const qp_gchar *)(L + (size_t)k * ld);
-              rb[st][0] = QP_LDNT(4, (const qp_gdouble *)(kb_ + vrb));
-              rb[st][1] = QP_LDNT(4, (const qp_gdouble *)(kb_ + vrb + o1));
-            }
-          };
-          auto mma = [&](const int st, const int buf, const int h) QP_ALWAYS_INLINE {
-            if (ACT) {
-              double pa[4];
-#pragma unroll
-              for (int ct = 0; ct < 4; ct++) pa[ct] = G.As[buf][4 * h + l4][16 * ct + l15];
-#pragma unroll
-              for (int ct = 0; ct < 4; ct++) acc[0][ct] = QP_MFMA_F64(pa[ct], rb[st][0], acc[0][ct]);
-#pragma unroll
-              for (int ct = 0; ct < 4; ct++) acc[1][ct] = QP_MFMA_F64(pa[ct], rb[st][1], acc[1][ct]);
-            }
-          };
-          stage_load(0);
-#pragma unroll
-          for (int st = 0; st < S; st++) loadb(st, 4 * st);
-          if (ACT) acc_load();
-          stage_store(0);
-          __syncthreads();
-          if (ACT) acc_mask();
-#pragma unroll 1
-          for (int kb = 0, c = 0; kb < J; kb += QP_FKC, c++) {
-            const int buf = c & 1;
-            const bool more = (kb + QP_FKC < J);
-            if (more) stage_load(kb + QP_FKC); /* in flight during this chunk's MFMAs */
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-              const int st = h % S;
-              mma(st, buf, h);
-              const int kn = kb + 4 * (h + S); /* the fragment S steps ahead (next chunk included; past the end: a harmless re-read) */
-              loadb(st, (kn < J) ? kn : (J - 4));
-            }
-            if (more) stage_store(buf ^ 1);
-            __syncthreads();
-          }
-        };
-        if (wact) kloop(std::integral_constant<int, 1>()); else kloop(std::integral_constant<int, 0>());
-      }
-      if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[4] += tq1 - tq0; tq0 = tq1; }
-      /* The in-block phases work on the 2 x 8 entries of ONE 32-column block as plain scalars e[t][i2] (i2 = 4 ct + r: column
-       * 4 i2 + l4 of the block), taken out of the accumulator tuples: element-wise updates of the 8-register MFMA tuples made the
-       * compiler keep (and spill) several versions of them. */
-      /* ---- a diagonal block: entries -> LDS, factorised by its wavefront in registers, L and d straight to HBM ---------- */
-      auto diag = [&](const int BLK, double (&e)[2][8]) QP_ALWAYS_INLINE {
-        FactorLds QP_LDS_AS &B = F.B[BLK];
-        const int J0 = J + NB * BLK, jb = BLK ? jb2 : jb1;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int i2 = 0; i2 < 8; i2++) {
-            const int rr = 16 * t + l15, cc = 4 * i2 + l4;
-            B.Ld[rr][cc] = (rr >= cc && rr < jb) ? e[t][i2] : ((rr == cc) ? 1.0 : 0.0);
-          }
-        QP_WAVE_SYNC();
-        if (QP_FDIAG_PRIO) QP_SETPRIO(3); /* the seven other wavefronts of the workgroup wait for this one */
-        if (QP_CALL_BLOCK()) factor_diag_block((char *)&B, (double *)(L + (size_t)J0 * ld + J0), ld, jb, (double *)(Dg + J0));
-        if (QP_FDIAG_PRIO) QP_SETPRIO(0);
-        QP_WAVE_SYNC();
-      };
-      /* ---- the in-block chain of one 32-column block, then l = u / d and the one store per entry ---- */
-      auto chain = [&](const int BLK, double (&e)[2][8]) QP_ALWAYS_INLINE {
-        FactorLds QP_LDS_AS &B = F.B[BLK];
-        const int J0 = J + NB * BLK;
-        /* Four columns per step: the columns 4 idx .. 4 idx + 3 are the SAME register in the four lane groups.  Every lane gathers the
-         * four values of its row (ds_bpermute), finishes them itself -- u0 = p0, u1 = p1 - u0 l10, u2 = (p2 - u0 l20) - u1 l21, ... :
-         * per entry the fmas of the column-by-column form, in the same order -- and applies the four to its own and its later columns
-         * (c ascending).  Eight serial steps per block instead of thirty-two: a step costs one LDS round trip (the gather; the entries
-         * of the diagonal block it needs are read next to it), and under the load of a second workgroup's sweep on the same CU that
-         * round trip is ~400 clk (the column-by-column form measured 35 us per pass). */
-#pragma unroll
-        for (int idx = 0; idx < 8; idx++) {
-          const int c0 = 4 * idx;
-          double nu[2][4]; /* -u of the four columns, both tiles */
-#pragma unroll
-          for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) nu[t][g] = -qp_bperm(e[t][idx], bp0 + 64 * g);
-          const double m10 = B.Ld[c0 + 1][c0], m20 = B.Ld[c0 + 2][c0], m21 = B.Ld[c0 + 2][c0 + 1];
-          const double m30 = B.Ld[c0 + 3][c0], m31 = B.Ld[c0 + 3][c0 + 1], m32 = B.Ld[c0 + 3][c0 + 2];
-#pragma unroll
-          for (int t = 0; t < 2; t++) { /* (nu holds -p on entry: u1 = p1 - u0 l10 = fma(-u0, l10, p1)) */
-            double u1 = QP_FMA(nu[t][0], m10, -nu[t][1]);
-            double u2 = QP_FMA(nu[t][0], m20, -nu[t][2]);
-            u2 = QP_FMA(-u1, m21, u2);
-            double u3 = QP_FMA(nu[t][0], m30, -nu[t][3]);
-            u3 = QP_FMA(-u1, m31, u3);
-            u3 = QP_FMA(-u2, m32, u3);
-            nu[t][1] = -u1; nu[t][2] = -u2; nu[t][3] = -u3;
-          }
-          /* i2 == idx: the lane's own column 4 idx + l4 receives the columns before it through the same four fmas -- the diagonal and
-           * the upper triangle of the staged block are zero (factor_diag_block clears the diagonal), so the terms k >= l4 add an exact
-           * zero and what is left is u_{l4}, bit for bit.  No select, no branch in the chain. */
-#pragma unroll
-          for (int i2 = idx; i2 < 8; i2++) {
-            const double lv0 = B.Ld[4 * i2 + l4][c0], lv1 = B.Ld[4 * i2 + l4][c0 + 1], lv2 = B.Ld[4 * i2 + l4][c0 + 2], lv3 = B.Ld[4 * i2 + l4][c0 + 3];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-              double a = e[t][i2];
-              a = QP_FMA(nu[t][0], lv0, a);
-              a = QP_FMA(nu[t][1], lv1, a);
-              a = QP_FMA(nu[t][2], lv2, a);
-              a = QP_FMA(nu[t][3], lv3, a);
-              e[t][i2] = a;
-            }
-            if (((i2 - idx) % QP_FCHG) == QP_FCHG - 1) QP_SCHED_BARRIER(); /* at most QP_FCHG registers' worth of block entries (8 VGPRs each) in flight */
-          }
-          QP_SCHED_BARRIER(); /* one step at a time: left alone the scheduler gathers the operands of several steps first and spills them */
-        }
-        /* l = u / d and the one store of the entry: uniform column base + per-lane byte offset, no masks on a tile inside the matrix */
-        const unsigned vs0 = (unsigned)(l4 * ld + row[0]) * 8u;
-        const bool fullst = QP_UNIFORM((int)((J + 16 * tile0 + 32 <= n) && (J0 + NB <= n))) != 0;
-#pragma unroll
-        for (int i2 = 0; i2 < 8; i2++) {
-          const int cc = 4 * i2 + l4, col = J0 + cc;
-          const double dvv = B.dv[cc];
-          qp_gchar *cp = (qp_gchar *)(L + (size_t)(J0 + 4 * i2) * ld);
-          const double lv0 = e[0][i2] * dvv, lv1 = e[1][i2] * dvv;
-          e[0][i2] = lv0;
-          e[1][i2] = lv1;
-          if (fullst) {
-            *(qp_gdouble *)(cp + vs0) = lv0;
-            *(qp_gdouble *)(cp + vs0 + 128) = lv1;
+  for (int J = 0; J < n; J += NB) {
+    const int jb = (n - J < NB) ? (n - J) : NB;
+    /* ---- (1) panel update on the matrix cores.  Left-looking over 64-column super-blocks: at the start of a
+     * super-block its 64 columns receive the contributions of ALL earlier columns (the panel is streamed once per
+     * 64 columns); its second 32-column block then only needs the 32 columns just finished. ---------------- */
+    {
+      const bool super = (J % (2 * NB)) == 0;
+      const int k0 = super ? 0 : J - NB, k1 = J;
+      if (k1 > k0) {
+        const int ntiles = (n - J + 15) / 16;
+        char *stage = lds_ + ((sizeof(FactorLds) + 15) & ~(size_t)15);
+        for (int tbase = 0; tbase < ntiles; tbase += QP_FNT * QP_NW) {
+          const int rem = ntiles - tbase;
+          const int ntj = (rem + QP_NW - 1) / QP_NW; /* same for every wavefront */
+          if (super) {
+            if (ntj <= 1) factor_panel_update<1, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+            else factor_panel_update<2, 4>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
           } else {
-            if (row[0] < n && col < n) *(qp_gdouble *)(cp + vs0) = lv0;
-            if (row[1] < n && col < n) *(qp_gdouble *)(cp + vs0 + 128) = lv1;
+            if (ntj <= 1) factor_panel_update<1, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
+            else factor_panel_update<2, 2>(L_, Dg_, stage, n, ld, J, tbase, k0, k1);
           }
         }
-      };
-      double e1[2][8]; /* the first block's entries */
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int i2 = 0; i2 < 8; i2++) e1[t][i2] = acc[t][i2 >> 2][i2 & 3];
-      if (first) {
-        if (diag1) diag(0, e1);
-        __syncthreads();
-        if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
+        if (tid == 0) { /* entries of L re-read: the panel rows once per pass group, the block rows once per pass */
+          const long long npass = (ntiles + QP_FNT * QP_NW - 1) / (QP_FNT * QP_NW);
+          tdbg[QPG_CNT_FACTOR_REREAD] += (long long)(n - J) * (k1 - k0) + npass * (super ? 2 * NB : NB) * (long long)(k1 - k0);
+        }
       }
-      const bool do1 = wact && !diag1;
-      if (do1) chain(0, e1);
-      if (has2) {
-        if (first) {
-          if (diag2) { /* the square under the first diagonal block as the operand of every wavefront's P4 */
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-              for (int i2 = 0; i2 < 8; i2++) {
-                const int k = 4 * i2 + l4;
-                F.Sq[k][16 * t + l15] = -(e1[t][i2] * F.B[0].dg[k]);
-              }
-          }
-          __syncthreads();
-        }
-        if (do1) { /* P4: the panel fragment of step h is the lane's own finished entry of column 4 h + l4 */
-#pragma unroll
-          for (int h = 0; h < NB / 4; h++) {
-            const double pa2 = F.Sq[4 * h + l4][l15], pa3 = F.Sq[4 * h + l4][16 + l15];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-              acc[t][2] = QP_MFMA_F64(pa2, e1[t][h], acc[t][2]);
-              acc[t][3] = QP_MFMA_F64(pa3, e1[t][h], acc[t][3]);
-            }
-          }
-        }
-        double e2[2][8]; /* the second block's entries */
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int i2 = 0; i2 < 8; i2++) e2[t][i2] = acc[t][2 + (i2 >> 2)][i2 & 3];
-        if (first) {
-          if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
-          if (diag2) diag(1, e2);
-          __syncthreads();
-          if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
-        }
-        if (do1 && !diag2) chain(1, e2);
-      }
-      if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
     }
+    __syncthreads();
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[4] += tq1 - tq0; tq0 = tq1; }
+    /* ---- (2) diagonal block: staged in LDS by all threads (rows beyond the matrix = identity), factorised by
+     * wavefront 0 in registers (factor_diag_block), written back by all threads ---------------------------------- */
+    for (int e = tid; e < NB * NB; e += QP_T) {
+      const int c = e / NB, r = e % NB;
+      F.Ld[r][c] = (r >= c && r < jb) ? L[(size_t)(J + c) * ld + (J + r)] : ((r == c) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wid == 0) factor_diag_block(lds_);
+    __syncthreads();
+    for (int e = tid; e < jb * jb; e += QP_T) {
+      const int c = e / jb, r = e % jb;
+      if (r > c) L[(size_t)(J + c) * ld + (J + r)] = F.Ld[r][c];
+    }
+    if (tid < jb) Dg[J + tid] = F.dg[tid];
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[5] += tq1 - tq0; tq0 = tq1; }
+    /* ---- (3) rows below the block: l_ic = (p_ic - sum_{c1<c} u_ic1 l_c,c1) / d_c ---------------- */
+    factor_panel_rows(L_, lds_, n, ld, J, jb);
+    __syncthreads();
+    if (tid == 0) { const long long tq1 = QP_CLOCK(); tdbg[6] += tq1 - tq0; tq0 = tq1; }
   }
   __syncthreads();
 }

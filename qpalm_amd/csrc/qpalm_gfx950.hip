@@ -24,7 +24,6 @@
 #define QP_USQ QP_USQ_512
 namespace qp512 {
 #include "qpalm_kernels.h"
-static_assert(sizeof(FusedFactorLds) + sizeof(FactorStage) + 64 <= QPG_LDS_DEFAULT, "the factorisation's LDS blocks fit the default dynamic LDS");
 }
 #undef QP_T
 #undef QP_KSEL
@@ -37,11 +36,11 @@ static_assert(sizeof(FusedFactorLds) + sizeof(FactorStage) + 64 <= QPG_LDS_DEFAU
 #undef QPALM_KKT_H
 #define QP_T 256
 #define QP_KSEL(RPT) 8
-#define QP_FKC 8 /* the fused factorisation keeps two diagonal blocks + the square's operand (26.5 KB) next to the staged chunk */
+#define QP_FKC 16
 #define QP_USQ 0
 namespace qp256 {
 #include "qpalm_kernels.h"
-static_assert(sizeof(UpdownLds<1, 8>) <= 38912 && sizeof(FusedFactorLds) + sizeof(FactorStage) + 64 <= 38912 && sizeof(SolveLds) + 8 * 256 <= 38912,
+static_assert(sizeof(UpdownLds<1, 8>) <= 38912 && sizeof(FactorLds) + sizeof(FactorStage) + 64 <= 38912 && sizeof(SolveLds) + 8 * 256 <= 38912,
               "the 256-thread instance runs with 38 KB of dynamic LDS");
 }
 #undef QP_T

@@ -106,6 +106,18 @@ def random_mpc_qp(T=10, nx=10, nu=5, seed=0, x_init_scale=1.0, x_init=None):
     return QP(n, A.shape[0], Qp, Qi, Qx, Ap, Ai, Ax, q, bmin, bmax)
 
 
+def config5_qp(n=5000, m=5000, seed=55):
+    """BASELINE.json config 5 ("nonconvex random QP n = 5000"): random_qp with every fifth diagonal entry of Q lowered by 2.5 x its
+    value (indefinite Hessian).  One definition for tests/test_coop.py, tools/ and the golden fixture tests/golden/config5_n5000.npz."""
+    p = random_qp(n, m, seed=seed, density_A=0.002, density_M=0.001)
+    Q = sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(n, n)).tolil()
+    for j in range(0, n, 5):
+        Q[j, j] = Q[j, j] - 2.5 * abs(Q[j, j])
+    Q = sp.csc_matrix(Q)
+    Q.sort_indices()
+    return QP(n, m, Q.indptr.astype(np.int64), Q.indices.astype(np.int64), Q.data.copy(), p.Ap, p.Ai, p.Ax, p.q, p.bmin, p.bmax)
+
+
 def replicated_qp(base, copies, seed=0, pert=0.05):
     """Block-diagonal QP made of `copies` randomly perturbed copies of `base` (a small fixture QP): a larger instance
     that keeps the base problem's behaviour (e.g. the reference's basic_qp reaches boost_gamma, iteration.c:158-211)."""
