@@ -180,6 +180,11 @@ int  qpg_batch_num_unfinished(qpg_batch *bt, qpg_int *count);
  * factor has at most 256 rows -- four workgroups per CU instead of two), dynamic LDS per workgroup.  No reference
  * counterpart (the reference runs one QP on one core); used by bench.py's per-phase bandwidth figures. */
 int  qpg_batch_launch_shape(qpg_batch *bt, qpg_int *workgroups, qpg_int *threads, qpg_int *lds_bytes);
+/* The sparse L D L' (round 5): replaces what solver_interface.c:319-370, 523-541 hands to cholmod_analyze / cholmod_factorize for
+ * factors that are sparse or have more than 8192 rows (context option "sparse_factor": -1 automatic for > 8192 rows, 1 always,
+ * 0 never; Schur path, no dual termination).  nnzL: entries of the member's strict lower triangle; device_bytes: the block that holds
+ * the symbolic arrays of all members and the values of all resident factors.  QPG_ERR_UNSUPPORTED on a batch with dense factors. */
+int  qpg_batch_sparse_info(qpg_batch *bt, qpg_int idx, qpg_int *nnzL, qpg_int *device_bytes);
 int  qpg_batch_update_settings(qpg_batch *bt, const QPGSettings *s);
 int  qpg_batch_update_bounds(qpg_batch *bt, const qpg_float *bmin, const qpg_float *bmax); /* [B][m] or NULL */
 int  qpg_batch_update_q(qpg_batch *bt, const qpg_float *q);                              /* [B][n] */

@@ -84,6 +84,14 @@ struct oq_workspace {
   oq_float lobpcg_lambda;
   oq_float *Hbuf; /* scratch n*n for forming Q + A'SA */
   oq_float *wbuf; /* scratch n for rank-1 vectors */
+  /* sparse-storage mode of the Schur factor (round 5): the SAME factorisation and solves on a compressed-column L -- what CHOLMOD's
+   * simplicial analyze / factorize / solve do -- for problems whose n^2 panel is out of reach (n = 20 000 .. 100 000).  Every entry
+   * receives the operations of the dense routines above in the same order (structural zeros are skipped, and a skipped operation adds
+   * an exact zero), so the dense mode pins it: tests/test_sparse_factor.py compares the two bit for bit.  In this mode every change
+   * of the active set or of sigma refactorises (no rank updates), which is what the engine's sparse factor does. */
+  int sparse_mode;
+  oq_int *sp_Lp, *sp_Li, *sp_Rp, *sp_Rk, *sp_Rpos; /* pattern of L by columns (strict lower, rows ascending) and by rows (columns ascending) */
+  oq_float *sp_Lx, *sp_D, *sp_y;                    /* values on that pattern, pivots, dense work vector (zero outside of use) */
   /* settings / solution / info */
   oq_settings settings;
   oq_float *sol_x, *sol_y;
@@ -667,6 +675,7 @@ void oq_cleanup(oq_workspace *w) {
   factor_free(&w->LD); factor_free(&w->LD_Q); factor_free(&w->LDK);
   free(w->kkt_state); free(w->rhs_kkt); free(w->sol_kkt); free(w->kkt_tmp);
   if (w->At.p) sp_free(&w->At);
+  free(w->sp_Lp); free(w->sp_Li); free(w->sp_Rp); free(w->sp_Rk); free(w->sp_Rpos); free(w->sp_Lx); free(w->sp_D); free(w->sp_y);
   free(w);
 }
 
@@ -779,6 +788,10 @@ void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
       w->reset_newton = 1;
     return;
   }
+  if (w->sparse_mode) { /* no rank updates on the sparse factor: any change of sigma refactorises (like the engine's sparse mode) */
+    if ((st->proximal && w->gamma < st->gamma_max) || w->nb_sigma_changed > 0) w->reset_newton = 1;
+    return;
+  }
   if ((st->proximal && w->gamma < st->gamma_max) ||
       (w->nb_sigma_changed > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), 0.25 * st->max_rank_update))) {
     w->reset_newton = 1;
@@ -829,6 +842,7 @@ static oq_float gershgorin_max_AtsigmaA(oq_workspace *w, const oq_int *fset, oq_
   return ub;
 }
 
+static oq_float sparse_gershgorin(oq_workspace *w, const oq_int *fset, oq_int nf); /* sparse-storage mode, below */
 static void boost_gamma(oq_workspace *w) { /* iteration.c:158-211 */
   size_t n = (size_t)w->n;
   oq_float prev = w->gamma;
@@ -837,7 +851,7 @@ static void boost_gamma(oq_workspace *w) { /* iteration.c:158-211 */
     oq_int nb = 0;
     for (oq_int i = 0; i < w->m; i++) if (w->active[i]) w->enter[nb++] = i; /* B4 */
     if (w->kkt_mode) w->gamma = 1e10; /* iteration.c:173-176 */
-    else w->gamma = OQ_MAX(w->settings.gamma_max, 1e14 / gershgorin_max_AtsigmaA(w, w->enter, nb));
+    else w->gamma = OQ_MAX(w->settings.gamma_max, 1e14 / (w->sparse_mode ? sparse_gershgorin(w, w->enter, nb) : gershgorin_max_AtsigmaA(w, w->enter, nb)));
     w->gamma_maxed = 1;
   } else w->gamma = 1e12;
   if (prev != w->gamma) {
@@ -848,15 +862,145 @@ static void boost_gamma(oq_workspace *w) { /* iteration.c:158-211 */
 }
 
 /* =========================================================================================
+ * sparse-storage mode (see oq_workspace.sparse_mode)
+ * ======================================================================================= */
+static int cmp_int(const void *a, const void *b) { oq_int x = *(const oq_int *)a, y = *(const oq_int *)b; return (x > y) - (x < y); }
+/* pattern of L for H = Q + A'A with ALL rows of A, natural ordering: struct(L_j) = struct(H_j) u U_{children} struct(L_c) \ {c} */
+static void sparse_analyze(oq_workspace *w) {
+  oq_int n = w->n;
+  const oq_sparse *Q = &w->Q, *A = &w->A;
+  oq_sparse T; memset(&T, 0, sizeof T);
+  sp_transpose(A, &T); /* n x m: column t = row t of A */
+  oq_int *Lp = izalloc((size_t)n + 1), *mark = izalloc((size_t)n), *head = izalloc((size_t)n), *next = izalloc((size_t)n);
+  size_t cap = (size_t)(Q->p[n] + A->p[n] + n + 16), nz = 0;
+  oq_int *Li = (oq_int *)malloc(cap * sizeof(oq_int)), *col = izalloc((size_t)n);
+  for (oq_int j = 0; j < n; j++) { mark[j] = -1; head[j] = -1; next[j] = -1; }
+  for (oq_int j = 0; j < n; j++) {
+    oq_int cnt = 0;
+    mark[j] = j;
+    for (oq_int k = Q->p[j]; k < Q->p[j + 1]; k++) { oq_int i = Q->i[k]; if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
+    for (oq_int p = A->p[j]; p < A->p[j + 1]; p++) {
+      oq_int t = A->i[p];
+      for (oq_int q = T.p[t]; q < T.p[t + 1]; q++) { oq_int i = T.i[q]; if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
+    }
+    for (oq_int c = head[j]; c >= 0; c = next[c])
+      for (oq_int e = Lp[c]; e < Lp[c + 1]; e++) { oq_int i = Li[e]; if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
+    qsort(col, (size_t)cnt, sizeof(oq_int), cmp_int);
+    if (nz + (size_t)cnt > cap) { cap = 2 * (nz + (size_t)cnt); Li = (oq_int *)realloc(Li, cap * sizeof(oq_int)); }
+    for (oq_int e = 0; e < cnt; e++) Li[nz + (size_t)e] = col[e];
+    nz += (size_t)cnt;
+    Lp[j + 1] = (oq_int)nz;
+    if (cnt) { next[j] = head[col[0]]; head[col[0]] = j; }
+  }
+  oq_int *Rp = izalloc((size_t)n + 1), *Rk = izalloc(nz), *Rpos = izalloc(nz), *cur = izalloc((size_t)n);
+  for (size_t e = 0; e < nz; e++) Rp[Li[e] + 1]++;
+  for (oq_int i = 0; i < n; i++) { Rp[i + 1] += Rp[i]; cur[i] = Rp[i]; }
+  for (oq_int k = 0; k < n; k++)
+    for (oq_int e = Lp[k]; e < Lp[k + 1]; e++) { oq_int dst = cur[Li[e]]++; Rk[dst] = k; Rpos[dst] = e; }
+  free(mark); free(head); free(next); free(col); free(cur); sp_free(&T);
+  w->sp_Lp = Lp; w->sp_Li = Li; w->sp_Rp = Rp; w->sp_Rk = Rk; w->sp_Rpos = Rpos;
+  w->sp_Lx = zalloc(nz); w->sp_D = zalloc((size_t)n); w->sp_y = zalloc((size_t)n);
+}
+static oq_int sparse_pos(const oq_workspace *w, oq_int i, oq_int j) { /* position of L(i, j), i > j */
+  const oq_int *base = w->sp_Li + w->sp_Lp[j];
+  const oq_int *hit = (const oq_int *)bsearch(&i, base, (size_t)(w->sp_Lp[j + 1] - w->sp_Lp[j]), sizeof(oq_int), cmp_int);
+  return (oq_int)(hit - w->sp_Li);
+}
+/* H = tril(Q) (+ tril(F F') over the active rows) (+ beta I) on L's pattern, then oq_dense_ldl_factor's up-looking recurrence row by
+ * row over the structural nonzeros only: the operations of oq_ldlcholQAtsigmaA / factor_sparse_lower, entry for entry */
+static void sparse_factor(oq_workspace *w, int with_AtSA, int add_beta, oq_float beta) {
+  oq_int n = w->n;
+  if (!w->sp_Lp) sparse_analyze(w);
+  oq_float *Lx = w->sp_Lx, *D = w->sp_D, *y = w->sp_y;
+  memset(Lx, 0, (size_t)w->sp_Lp[n] * sizeof(oq_float));
+  memset(D, 0, (size_t)n * sizeof(oq_float));
+  if (with_AtSA) {
+    const oq_sparse *F = &w->At_sqrt_sigma;
+    for (oq_int t = 0; t < w->m; t++) {
+      if (!w->active[t]) continue;
+      for (oq_int b = F->p[t]; b < F->p[t + 1]; b++) {
+        oq_float vb = F->x[b]; oq_int cb = F->i[b];
+        for (oq_int a = F->p[t]; a < F->p[t + 1]; a++) {
+          oq_int ra = F->i[a];
+          if (ra == cb) D[cb] += F->x[a] * vb; else if (ra > cb) Lx[sparse_pos(w, ra, cb)] += F->x[a] * vb;
+        }
+      }
+    }
+  }
+  const oq_sparse *Q = &w->Q;
+  for (oq_int j = 0; j < n; j++)
+    for (oq_int k = Q->p[j]; k < Q->p[j + 1]; k++) {
+      oq_int i = Q->i[k];
+      if (i == j) D[j] = Q->x[k] + D[j]; else if (i > j) { oq_int e = sparse_pos(w, i, j); Lx[e] = Q->x[k] + Lx[e]; }
+    }
+  if (add_beta) for (oq_int j = 0; j < n; j++) D[j] += beta;
+  for (oq_int k = 0; k < n; k++) { /* row k: its structural nonzeros are the columns Rk[Rp[k] .. Rp[k+1]), ascending */
+    oq_float dk = D[k];
+    for (oq_int r = w->sp_Rp[k]; r < w->sp_Rp[k + 1]; r++) y[w->sp_Rk[r]] = Lx[w->sp_Rpos[r]];
+    for (oq_int r = w->sp_Rp[k]; r < w->sp_Rp[k + 1]; r++) {
+      oq_int i = w->sp_Rk[r];
+      oq_float yi = y[i];
+      for (oq_int e = w->sp_Lp[i]; e < w->sp_Lp[i + 1]; e++) { oq_int rr = w->sp_Li[e]; if (rr >= k) break; y[rr] -= Lx[e] * yi; }
+      oq_float lki = yi / D[i];
+      dk -= lki * yi;
+      Lx[w->sp_Rpos[r]] = lki;
+    }
+    for (oq_int r = w->sp_Rp[k]; r < w->sp_Rp[k + 1]; r++) y[w->sp_Rk[r]] = 0;
+    D[k] = dk;
+  }
+}
+static void sparse_solve(oq_workspace *w, oq_float *b) { /* oq_dense_ldl_solve on the compressed columns */
+  oq_int n = w->n;
+  for (oq_int j = 0; j < n; j++) { oq_float yj = b[j]; for (oq_int e = w->sp_Lp[j]; e < w->sp_Lp[j + 1]; e++) b[w->sp_Li[e]] -= w->sp_Lx[e] * yj; }
+  for (oq_int j = 0; j < n; j++) b[j] /= w->sp_D[j];
+  for (oq_int j = n - 1; j >= 0; j--) { oq_float xj = b[j]; for (oq_int e = w->sp_Lp[j]; e < w->sp_Lp[j + 1]; e++) xj -= w->sp_Lx[e] * b[w->sp_Li[e]]; b[j] = xj; }
+}
+/* gershgorin_max_AtsigmaA without the n x n buffer: one column of C = F F' at a time in the dense work vector, summed over the touched
+ * rows in ascending order (the dense routine walks i = 0 .. n-1 over its pattern map) */
+static oq_float sparse_gershgorin(oq_workspace *w, const oq_int *fset, oq_int nf) {
+  oq_int n = w->n;
+  if (!w->sp_Lp) sparse_analyze(w);
+  unsigned char *isact = (unsigned char *)calloc(nz1((size_t)w->m), 1);
+  for (oq_int f = 0; f < nf; f++) isact[fset[f]] = 1;
+  const oq_sparse *F = &w->At_sqrt_sigma, *A = &w->A;
+  oq_float *c = w->sp_y, ub = 0;
+  oq_int *touched = izalloc((size_t)n), *mark = izalloc((size_t)n);
+  for (oq_int j = 0; j < n; j++) mark[j] = -1;
+  for (oq_int j = 0; j < n; j++) {
+    oq_int nt = 0;
+    for (oq_int p = A->p[j]; p < A->p[j + 1]; p++) { /* the rows t with F_jt != 0 structurally, ascending */
+      oq_int t = A->i[p];
+      if (!isact[t]) continue;
+      oq_float vb = 0;
+      for (oq_int b = F->p[t]; b < F->p[t + 1]; b++) if (F->i[b] == j) vb = F->x[b];
+      for (oq_int a = F->p[t]; a < F->p[t + 1]; a++) {
+        oq_int i = F->i[a];
+        if (mark[i] != j) { mark[i] = j; touched[nt++] = i; }
+        c[i] += F->x[a] * vb;
+      }
+    }
+    qsort(touched, (size_t)nt, sizeof(oq_int), cmp_int);
+    oq_float center = 0, radius = 0;
+    for (oq_int e = 0; e < nt; e++) { oq_int i = touched[e]; if (i == j) center = c[i]; else radius += OQ_ABS(c[i]); c[i] = 0; }
+    w->temp_n[j] = center; w->neg_dphi[j] = radius;
+    ub = (j == 0) ? center + radius : OQ_MAX(ub, center + radius);
+  }
+  free(isact); free(touched); free(mark);
+  return ub;
+}
+
+/* =========================================================================================
  * solver_interface.c restated (CHOLMOD branch)
  * ======================================================================================= */
 void oq_ldlchol(const oq_sparse *M, oq_workspace *w) { /* solver_interface.c:319-370 */
+  if (w->sparse_mode && M == &w->Q) { sparse_factor(w, 0, (int)w->settings.proximal, 1.0 / w->gamma); return; }
   factor_sparse_lower(w, M, &w->LD, (int)w->settings.proximal, 1.0 / w->gamma);
 }
 
 void oq_ldlcholQAtsigmaA(oq_workspace *w) { /* solver_interface.c:372-405 */
   oq_int n = w->n, nb = 0;
   for (oq_int i = 0; i < w->m; i++) if (w->active[i]) w->enter[nb++] = i; /* B4: clobbers enter[] */
+  if (w->sparse_mode) { sparse_factor(w, 1, (int)w->settings.proximal, 1.0 / w->gamma); return; }
   factor_alloc(&w->LD, n);
   oq_float *H = w->LD.L;
   memset(H, 0, (size_t)(n * n) * sizeof(oq_float));
@@ -928,6 +1072,7 @@ void oq_ldlsolveLD_neg_dphi(oq_workspace *w) { /* solver_interface.c:505-519 */
   vec_cp(w->dphi, w->neg_dphi, n);
   oq_vec_self_mult_scalar(w->neg_dphi, -1, n);
   vec_cp(w->neg_dphi, w->d, n);
+  if (w->sparse_mode) sparse_solve(w, w->d); else
   oq_dense_ldl_solve(w->n, w->LD.L, w->n, w->LD.D, w->d);
   w->n_solve++;
 }
@@ -1103,7 +1248,8 @@ void oq_newton_set_direction(oq_workspace *w) { /* newton.c:17-120 */
     return;
   }
   if ((w->reset_newton && w->nb_active) ||
-      (w->nb_enter + w->nb_leave) > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), st->max_rank_update)) {
+      (w->nb_enter + w->nb_leave) > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), st->max_rank_update) ||
+      (w->sparse_mode && w->nb_active && (w->nb_enter + w->nb_leave) > 0)) { /* (sparse mode: a changed active set refactorises) */
     oq_ldlcholQAtsigmaA(w); w->n_refactor++; w->last_fact = 1;
   } else if (w->nb_active) {
     w->last_fact = 0;
@@ -1597,6 +1743,7 @@ void oq_set_scalar(oq_workspace *w, const char *name, oq_float v) {
   else if (!strcmp(name, "tau")) w->tau = v;
   else if (!strcmp(name, "proximal")) w->settings.proximal = (oq_int)v;
   else if (!strcmp(name, "reset_newton")) w->reset_newton = (int)v;
+  else if (!strcmp(name, "sparse_mode")) w->sparse_mode = (v != 0) && !w->kkt_mode && !w->settings.enable_dual_termination; /* before the first solve */
   else if (!strcmp(name, "eps_abs_in")) w->eps_abs_in = v;
   else if (!strcmp(name, "eps_rel_in")) w->eps_rel_in = v;
   else if (!strcmp(name, "nb_sigma_changed")) w->nb_sigma_changed = (oq_int)v; /* op-level tests of ldlupdate_sigma_changed */
@@ -1652,7 +1799,14 @@ const oq_float *oq_get_kkt_factor(const oq_workspace *w, const oq_float **D, oq_
   if (ld) *ld = w->n + w->m;
   return w->LDK.L;
 }
-const oq_float *oq_get_factor(const oq_workspace *w, const oq_float **D, oq_int *ld) {
+const oq_float *oq_get_factor(const oq_workspace *w_, const oq_float **D, oq_int *ld) {
+  oq_workspace *w = (oq_workspace *)w_;
+  if (w->sparse_mode && w->sp_Lp) { /* tests of the sparse-storage mode on small problems: the compressed columns spread out into the dense layout */
+    oq_int n = w->n;
+    factor_alloc(&w->LD, n);
+    memset(w->LD.L, 0, (size_t)(n * n) * sizeof(oq_float));
+    for (oq_int j = 0; j < n; j++) { w->LD.D[j] = w->sp_D[j]; for (oq_int e = w->sp_Lp[j]; e < w->sp_Lp[j + 1]; e++) w->LD.L[w->sp_Li[e] + j * n] = w->sp_Lx[e]; }
+  }
   if (D) *D = w->LD.D;
   if (ld) *ld = w->n;
   return w->LD.L;

@@ -34,6 +34,7 @@ namespace qp512 {
 #undef QPALM_DENSE_H
 #undef QPALM_ITER_H
 #undef QPALM_KKT_H
+#undef QPALM_SPARSE_H
 #define QP_T 256
 #define QP_KSEL(RPT) 8
 #define QP_FKC 16

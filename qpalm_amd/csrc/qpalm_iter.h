@@ -336,6 +336,11 @@ QPP int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
   if (V.offload && V.update_rank_threshold >= 0) thr = qmin(thr, (double)V.update_rank_threshold); /* coop mode: beyond its threshold the factor is rebuilt by many workgroups
                                                                         instead of updated by one (speed policy, same matrix) */
   int nupd = 0;
+  if (V.sparse) { /* sparse factor (qpalm_sparse.h): no rank updates -- any change of sigma refactorises at the next Newton step */
+    if ((qp_prox(st, I.s) && I.s.gamma < qp_gamma_max(st, I.s)) || nchg > 0) { if (tid == 0) I.s.reset_newton = 1; }
+    __syncthreads();
+    return 0;
+  }
   if (V.kkt) {
     /* FACTORIZE_KKT (iteration.c:135-144, solver_interface.c:463-481): every branch that changes anything ends in
      * reset_newton = TRUE; the reference's rank-1 correction is applied at row pinv[row] (a variable's row) and is
@@ -611,12 +616,14 @@ QPP double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const
 }
 
 #include "qpalm_kkt.h"
+#include "qpalm_sparse.h"
 
 /* =============================================================================================
  * the loop body of qpalm_solve (src/qpalm.c:484-711) for one QP; runs at most `budget` iterations
  * =========================================================================================== */
 template <int RPT>
 QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, IterShared &I, char *lds) {
+  constexpr bool SPARSE = (RPT == QPG_RPT_SPARSE);
   const qpg_settings &st = *V.settings;
   QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x;
@@ -911,6 +918,14 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     }
     const long long t0 = QP_CLOCK();
     double gersh_ub = 0.0;
+    if constexpr (SPARSE) {
+      /* sparse factor (qpalm_sparse.h): every change of the matrix refactorises -- no rank updates -- and a change of sigma marks
+       * the factor stale, as the reference does under FACTORIZE_KKT (iteration.c:135-144) */
+      const SpArrays SP = sp_arrays(V, b, slot, Dg);
+      if (la == 2) { la = 1; action = 1; }
+      if (la == 1 || la == 3) sp_factor(V, b, n, SP, la == 1, prox != 0, gam);
+      else if (la == 5) gersh_ub = sp_gershgorin(V, b, n, SP, I.S);
+    } else
     if (resume) {
       if (la == 7) { /* LD_Q is ready (qpalm.c:459-468) */
         const double dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
@@ -959,6 +974,10 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     } else if (la == 5 || la == 6) dev_boost_gamma_apply(V, a, I, gersh_ub);
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
+      if constexpr (SPARSE) {
+        for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
+        sp_solve(n, sp_arrays(V, b, slot, Dg), a.d());
+      } else
       if (!V.kkt && !resume) {
         const bool fused = (RPT > 0) && !QP_NOFUSE && (action == 2) && !V.offload;
         if (!fused) for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;

@@ -1,0 +1,176 @@
+/*
+ * qpalm_sparse.h -- the factor of Q + A' Sigma_act A (+ I / gamma) as a SPARSE L D L' (round 5; VERDICT round 4, row h).
+ *
+ * Replaces src/solver_interface.c:319-370, 505-541 (ldlchol / ldlcholQAtsigmaA / ldlsolveLD_neg_dphi: what the reference hands to
+ * CHOLMOD's analyze + factorize + solve) for QPs whose Schur complement is sparse or has more rows than a dense panel allows
+ * (8192): device memory per QP is proportional to nnz(L), not n^2.
+ *
+ *  - Symbolic analysis once per QP on the host (qpalm_capi.inc: sparse_analyze): pattern of Q + A'A with ALL rows of A (a superset
+ *    of every active set's pattern, so the structure never changes while constraints enter and leave), elimination tree, pattern of
+ *    L by columns (strict lower part, rows ascending), the same entries by rows (column + position in the column arrays, columns
+ *    ascending) and the level sets of the elimination tree.  Natural ordering: what the reference configures
+ *    (solver_interface.c:530-540, c->nmethods = 1, method[0].ordering = CHOLMOD_NATURAL).
+ *  - Numeric factorisation: left-looking by columns, the columns of one level of the elimination tree in parallel (one wavefront
+ *    per column, lanes over the entries), a level ends with a workgroup barrier.  A column is assembled AND updated in a dense work
+ *    vector of its wavefront (HBM, n doubles, zero outside of use): A' Sigma A first (active rows t of A(:, j) ascending, as
+ *    form_schur), then Q, then 1 / gamma on the diagonal; then  w_i -= l_ik (l_jk d_k)  for the columns k of row j's structure,
+ *    ascending; then d_j = w_j, l_ij = w_i / d_j.  Assembly and factorisation are one pass: H never exists in memory.
+ *  - Triangular solves in place on the right-hand side in HBM: forward by rows (x_j = b_j - sum_k l_jk x_k, k ascending: the
+ *    order of the column-oriented loop of cholmod_solve), levels ascending, one thread per row; D; backward by columns, levels
+ *    descending.
+ *  - Changes of the active set or of sigma REFACTORISE (the reference's own behaviour under FACTORIZE_KKT, iteration.c:135-144, and
+ *    for more than max_rank_update changes): rank updates along the elimination-tree paths are not built.
+ * One workgroup per QP like the dense engine: batches of sparse QPs fill the chip; a single large sparse QP runs at the latency of
+ * its level chain (a band matrix has n levels).  DESIGN.md section 2.
+ */
+#ifndef QPALM_SPARSE_H
+#define QPALM_SPARSE_H
+
+struct SpArrays { /* this QP's symbolic arrays + this slot's values and work vectors */
+  const int *Lp, *Li, *Rp, *Rk, *Rpos, *levptr, *levcol;
+  int nlev;
+  double *Lx, *Dg, *wv;
+};
+QPD SpArrays sp_arrays(const qpg_view &V, int b, int slot, double *Dg) {
+  SpArrays s;
+  s.Lp = V.sp_Lp + (size_t)b * (V.n + 1); s.Li = V.sp_Li + (size_t)b * V.sp_nnzL;
+  s.Rp = V.sp_Rp + (size_t)b * (V.n + 1); s.Rk = V.sp_Rk + (size_t)b * V.sp_nnzL; s.Rpos = V.sp_Rpos + (size_t)b * V.sp_nnzL;
+  s.levptr = V.sp_levptr + (size_t)b * (V.n + 1); s.levcol = V.sp_levcol + (size_t)b * V.n;
+  s.nlev = V.sp_nlev[b];
+  s.Lx = V.sp_Lx + (size_t)slot * V.sp_nnzL; s.Dg = Dg; s.wv = V.sp_wv + (size_t)slot * QP_NW * V.n;
+  return s;
+}
+
+/* H = Q (+ A' Sigma_act A) (+ I / gamma) assembled column by column and factorised in the same pass (see the header).
+ * Q_only_values: the second resident factor LD_Q of the dual objective is not supported in sparse mode (qpg_batch_create refuses). */
+QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, bool with_AtSA, bool proximal, double gamma) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
+  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
+  const double *Atss = V.Atss + (size_t)b * V.nnzA;
+  const int *Ainv = V.Ainv + (size_t)b * V.nnzA;
+  const int *Qp = V.Qp + (size_t)b * (V.n + 1), *Qi = V.Qi + (size_t)b * V.nnzQ;
+  const double *Qx = V.Qx + (size_t)b * V.nnzQ;
+  const int *active = V.active + (size_t)b * V.m;
+  double *w = S.wv + (size_t)wid * n; /* this wavefront's work vector: zero on entry, zero again when the column is done */
+  __syncthreads();
+  for (int lev = 0; lev < S.nlev; lev++) {
+    const int c0 = S.levptr[lev], c1 = S.levptr[lev + 1];
+    for (int c = c0 + wid; c < c1; c += QP_NW) {
+      const int j = S.levcol[c];
+      const int e0 = S.Lp[j], e1 = S.Lp[j + 1];
+      /* ---- A' Sigma A, column j: active rows t ascending, lanes over the entries of row t (distinct columns i: no conflicts) ---- */
+      if (with_AtSA) {
+        for (int p = Ap[j]; p < Ap[j + 1]; p++) {
+          const int t = Ai[p];
+          if (!active[t]) continue;
+          const double vj = Atss[Ainv[p]];
+          for (int q = Atp[t] + lane; q < Atp[t + 1]; q += 64) {
+            const int i = Ati[q];
+            if (i >= j) w[i] += Atss[q] * vj;
+          }
+          QP_WAVE_SYNC();
+        }
+      }
+      /* ---- + Q(:, j), + 1 / gamma ---- */
+      for (int k = Qp[j] + lane; k < Qp[j + 1]; k += 64) {
+        const int i = Qi[k];
+        if (i >= j) w[i] = Qx[k] + w[i];
+      }
+      QP_WAVE_SYNC();
+      if (proximal && lane == 0) w[j] += 1.0 / gamma;
+      QP_WAVE_SYNC();
+      /* ---- left-looking updates: every column k < j with l_jk != 0, ascending ---- */
+      for (int r = S.Rp[j]; r < S.Rp[j + 1]; r++) {
+        const int k = S.Rk[r], pos = S.Rpos[r];
+        const double ljk = S.Lx[pos];
+        const double mk = ljk * S.Dg[k];
+        if (lane == 0) w[j] = QP_FMA(-ljk, mk, w[j]);
+        const int k1 = S.Lp[k + 1];
+        for (int e = pos + 1 + lane; e < k1; e += 64) { /* rows below j of column k: they all belong to column j's pattern */
+          const int i = S.Li[e];
+          w[i] = QP_FMA(-S.Lx[e], mk, w[i]);
+        }
+        QP_WAVE_SYNC();
+      }
+      /* ---- pivot and column; the work vector goes back to zero ---- */
+      const double dj = w[j];
+      QP_WAVE_SYNC();
+      for (int e = e0 + lane; e < e1; e += 64) {
+        const int i = S.Li[e];
+        S.Lx[e] = w[i] / dj;
+        w[i] = 0.0;
+      }
+      if (lane == 0) { S.Dg[j] = dj; w[j] = 0.0; }
+      QP_WAVE_SYNC();
+    }
+    __syncthreads();
+  }
+}
+
+/* max_j (C_jj + sum_{i != j} |C_ij|),  C = A' Sigma_act A  (gershgorin_max of nonconvex.c:185-210, used by boost_gamma): full
+ * columns in the work vectors, one wavefront per column */
+QPN double sp_gershgorin(const qpg_view &V, int b, const int n, const SpArrays &S, QpShared &Sh) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
+  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
+  const double *Atss = V.Atss + (size_t)b * V.nnzA;
+  const int *Ainv = V.Ainv + (size_t)b * V.nnzA;
+  const int *active = V.active + (size_t)b * V.m;
+  double *w = S.wv + (size_t)wid * n;
+  double gmax = -1e300;
+  __syncthreads();
+  for (int j = wid; j < n; j += QP_NW) {
+    for (int p = Ap[j]; p < Ap[j + 1]; p++) {
+      const int t = Ai[p];
+      if (!active[t]) continue;
+      const double vj = Atss[Ainv[p]];
+      for (int q = Atp[t] + lane; q < Atp[t + 1]; q += 64) w[Ati[q]] += Atss[q] * vj;
+      QP_WAVE_SYNC();
+    }
+    const double cjj = w[j];
+    QP_WAVE_SYNC();
+    if (lane == 0) w[j] = 0.0;
+    QP_WAVE_SYNC();
+    double rad = 0.0;
+    for (int p = Ap[j]; p < Ap[j + 1]; p++) { /* every touched entry is summed once: it is cleared when it is first met */
+      const int t = Ai[p];
+      if (!active[t]) continue;
+      for (int q = Atp[t] + lane; q < Atp[t + 1]; q += 64) { const int i = Ati[q]; rad += qabs(w[i]); w[i] = 0.0; }
+      QP_WAVE_SYNC();
+    }
+    rad = wave_sum(rad);
+    const double ub = cjj + rad;
+    gmax = (ub > gmax) ? ub : gmax;
+  }
+  double vm[1] = {gmax}, vs[1] = {0.0};
+  block_reduce<1, 0>(Sh, vm, vs);
+  return vm[0];
+}
+
+/* x <- (L D L')^-1 x, in place in HBM */
+QPN void sp_solve(const int n, const SpArrays &S, double *x) {
+  __syncthreads();
+  for (int lev = 0; lev < S.nlev; lev++) { /* forward: a row needs the rows of its structure, which sit in earlier levels */
+    for (int c = S.levptr[lev] + (int)threadIdx.x; c < S.levptr[lev + 1]; c += QP_T) {
+      const int j = S.levcol[c];
+      double v = x[j];
+      for (int r = S.Rp[j]; r < S.Rp[j + 1]; r++) v -= S.Lx[S.Rpos[r]] * x[S.Rk[r]];
+      x[j] = v;
+    }
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < n; j += QP_T) x[j] = x[j] / S.Dg[j];
+  __syncthreads();
+  for (int lev = S.nlev - 1; lev >= 0; lev--) { /* backward: a column needs the rows of its pattern (ancestors: later levels) */
+    for (int c = S.levptr[lev] + (int)threadIdx.x; c < S.levptr[lev + 1]; c += QP_T) {
+      const int j = S.levcol[c];
+      double v = x[j];
+      for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) v -= S.Lx[e] * x[S.Li[e]];
+      x[j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+#endif

@@ -117,11 +117,19 @@ typedef struct {
   int32_t *kkt_state; /* [B][m] 0 unit diagonal, 1 row present, 2 deleted by row_del (solver_interface.c:151-156,226-235) */
   double *Wst; /* [nslots][wst_stride]: staging of the rank-update vectors, dummy cells, exported tables (QPG_WST_STRIDE) */
   double *op_in, *op_out; /* [max(n,m)] scratch of the single-QP boundary operations */
+  /* sparse factor (qpalm_sparse.h; NULL / 0 in the dense modes): symbolic arrays per QP with the batch's strides, values per slot */
+  int32_t sparse, sp_nnzL;  /* sp_nnzL: stride of the entry arrays = the largest nnz(L) of the batch */
+  int32_t *sp_Lp, *sp_Li;   /* [B][n+1], [B][sp_nnzL]: strict lower pattern of L by columns, rows ascending */
+  int32_t *sp_Rp, *sp_Rk, *sp_Rpos; /* [B][n+1], [B][sp_nnzL] x 2: the same entries by rows: column k and position in column k's arrays, k ascending */
+  int32_t *sp_levptr, *sp_levcol, *sp_nlev; /* [B][n+1], [B][n], [B]: level sets of the elimination tree */
+  double *sp_Lx;            /* [nslots][sp_nnzL] */
+  double *sp_wv;            /* [nslots][wavefronts][n] dense work vectors of the factorisation (zero outside of use) */
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */
   int32_t *queue; /* [64 + QPG_CU_KEYS]: [0] work-queue head; [64 + key] workgroups that have arrived on compute unit `key` in this launch */
 } qpg_view;
 
+#define QPG_RPT_SPARSE 8 /* template argument of k_solve / dev_solve that selects the sparse factor (the dense instances use 0, 1, 2, 4) */
 #define QPG_KMAX 16 /* ranks per sweep of the large-factor and coop-mode sweeps */
 #define QPG_KWST 32 /* dense update vectors the staging area of a slot holds = most ranks per sweep of dense_updown */
 #define QPG_DUMMY 4096 /* doubles per slot that masked-off rows load from / store to */

@@ -118,6 +118,61 @@ def config5_qp(n=5000, m=5000, seed=55):
     return QP(n, m, Q.indptr.astype(np.int64), Q.indices.astype(np.int64), Q.data.copy(), p.Ap, p.Ai, p.Ax, p.q, p.bmin, p.bmax)
 
 
+def sparse_qp(n, kind="banded", seed=0, band=3, block=8, rows_per_block=4):
+    """Large SPARSE convex QPs whose Schur complement Q + A'A stays sparse under the natural ordering (round 5: the sparse factor).
+      banded:  Q tridiagonal-dominant with `band` sub-diagonals, A = two-variable difference rows x_i - x_{i+1} in [-1, 1] plus box rows
+               on every third variable (the elimination tree is a chain: n levels);
+      blocks:  block-diagonal Q with dense `block` x `block` blocks, `rows_per_block` constraints inside each block (a forest of
+               n / block small trees: `block` levels, thousands of columns per level);
+      arrow:   banded, plus one dense last row / column of Q (every column of L gets one more entry)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows, cols, vals = [], [], []
+    if kind in ("banded", "arrow"):
+        for k in range(1, band + 1):
+            v = 0.3 * rng.standard_normal(n - k) / k
+            rows += list(range(k, n)); cols += list(range(0, n - k)); vals += list(v)
+        if kind == "arrow":
+            v = 0.05 * rng.standard_normal(n - band - 1)
+            rows += [n - 1] * (n - band - 1); cols += list(range(0, n - band - 1)); vals += list(v)
+        Lo = sp.csc_matrix((vals, (rows, cols)), shape=(n, n))
+        S = Lo + Lo.T
+        Qf = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 1.0)).tocsc()
+        ar, ac, av = [], [], []
+        m = 0
+        for i in range(0, n - 1, 2):            # difference rows
+            ar += [m, m]; ac += [i, i + 1]; av += [1.0, -1.0]; m += 1
+        for i in range(0, n, 3):                # box rows
+            ar.append(m); ac.append(i); av.append(1.0); m += 1
+        A = sp.csc_matrix((av, (ar, ac)), shape=(m, n))
+        bmin, bmax = -0.5 * rng.random(m), 0.5 * rng.random(m)
+    elif kind == "blocks":
+        nb = n // block
+        n = nb * block
+        blocks = []
+        ar, ac, av = [], [], []
+        m = 0
+        for b in range(nb):
+            M = rng.standard_normal((block, block)) * 0.3
+            Sb = 0.5 * (M + M.T)
+            blocks.append(Sb + np.diag(np.abs(Sb).sum(axis=1) + 1.0))
+            for r in range(rows_per_block):
+                idx = rng.choice(block, size=min(3, block), replace=False)
+                for i in idx:
+                    ar.append(m); ac.append(b * block + int(i)); av.append(float(rng.standard_normal()))
+                m += 1
+        Qf = sp.block_diag(blocks, format="csc")
+        A = sp.csc_matrix((av, (ar, ac)), shape=(m, n))
+        bmin, bmax = -rng.random(m), rng.random(m)
+    else:
+        raise ValueError(kind)
+    A.sum_duplicates(); A.sort_indices()
+    Ql = sp.tril(Qf).tocsc(); Ql.sort_indices()
+    q = rng.standard_normal(n)
+    Qp, Qi, Qx = _csc(Ql)
+    Ap, Ai, Ax = _csc(A)
+    return QP(n, A.shape[0], Qp, Qi, Qx, Ap, Ai, Ax, q, bmin, bmax)
+
+
 def replicated_qp(base, copies, seed=0, pert=0.05):
     """Block-diagonal QP made of `copies` randomly perturbed copies of `base` (a small fixture QP): a larger instance
     that keeps the base problem's behaviour (e.g. the reference's basic_qp reaches boost_gamma, iteration.c:158-211)."""

@@ -151,6 +151,12 @@ class QpalmBatch:
         self._check(self.L.qpg_batch_launch_shape(self.h, C.byref(w), C.byref(t), C.byref(l)))
         return int(w.value), int(t.value), int(l.value)
 
+    def sparse_info(self, b=0):
+        """(nnz(L) of member b's sparse factor, bytes of the device block of all sparse factors); raises on a batch with dense factors"""
+        z, d = capi.c_int(0), capi.c_int(0)
+        self._check(self.L.qpg_batch_sparse_info(self.h, int(b), C.byref(z), C.byref(d)))
+        return int(z.value), int(d.value)
+
     def num_unfinished(self):
         c = capi.c_int(0)
         self._check(self.L.qpg_batch_num_unfinished(self.h, C.byref(c)))
