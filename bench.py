@@ -75,13 +75,13 @@ def parse_args(argv=None):
     ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
     ap.add_argument("--narrow-rows", type=int, default=1, help="0: Schur assembly with one wavefront per column also for small QPs (A/B)")
     ap.add_argument("--place-panel-wave", type=int, default=-1, help="0: every workgroup runs its serial chains on wavefront 0; 1: panel waves placed on SIMDs 0 / 1; 2: + row ownership by SIMD (A/B; default: the library's)")
-    ap.add_argument("--sweep-ranks", type=int, default=0, help="most ranks per sweep of the rank update: 16 or 32 (A/B; 0: library default = 32)")
+    ap.add_argument("--sweep-ranks", type=int, default=0, help="most ranks per sweep of the rank update: 16 or 32 (A/B; 0: library default = 16)")
     ap.add_argument("--kkt-compact", type=int, default=-1, help="KKT mode: 0 = factorise the whole (n+m) panel with its unit rows (A/B; default: the active rows only)")
     ap.add_argument("--ld-align", type=int, default=0, help="leading dimension of the factor panels rounded up to this many doubles (A/B; 0: library default = 16)")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
-    ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/ab.sh)")
+    ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/scratch/ab.sh)")
     ap.add_argument("--traffic-json", default=None,
-                    help="PMC summary written by tools/round_artifacts.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                    help="PMC summary written by tools/evidence/round_artifacts.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                          "command on the same box).  Without it roofline.traffic is null: a plain run measures no counters.  With it, "
                          "the figure is quoted only if the hash of the kernel sources AND of the built library recorded in the summary "
                          "equal this tree's and the workload matches")
@@ -495,13 +495,19 @@ def worker(args):
         ldl_bytes = nsl * model0["b_solve"]
         traffic = None
         traffic_src = None
-        if args.traffic_json and world == 1:
+        # the PMC summary of the SAME build (tools/evidence/round_artifacts.sh writes it, separate rocprofv3 --pmc passes): --traffic-json names
+        # one; without the flag the committed summaries under profiles/ are tried, newest round first.  Quoted only when the hashes of the
+        # kernel sources and of the loaded library recorded in the summary equal this run's (else roofline.traffic stays null).
+        import glob
+        cands = [args.traffic_json] if args.traffic_json else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final", "k_solve_pmc_traffic.json")), reverse=True)
+        for cand in (cands if world == 1 else []):
             try:
-                with open(args.traffic_json) as f:
+                with open(cand) as f:
                     pj = json.load(f)
                 if pj["source_sha256"] == source_sha256() and pj.get("lib_sha256") == lib_sha256(args.lib) and (pj["batch"], pj["n"], pj["m"]) == (B, n, m):
                     traffic = float(pj["traffic_bytes_per_launch"])
-                    traffic_src = os.path.relpath(args.traffic_json, ROOT)
+                    traffic_src = os.path.relpath(cand, ROOT)
+                    break
             except Exception:
                 traffic = None
         out = {

@@ -39,7 +39,7 @@ def build_hip(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     # -save-temps into a scratch directory: the device assembly is checked for a ROCm 7.2 register-allocator fault
-    # (tools/scan_exec_prologue.py: register copies ahead of an exec restore; round 3's wrong dual objective on the GPU)
+    # (tools/evidence/scan_exec_prologue.py: register copies ahead of an exec restore; round 3's wrong dual objective on the GPU)
     import shutil
     import tempfile
     tmp = tempfile.mkdtemp(prefix="qpalm_build_")

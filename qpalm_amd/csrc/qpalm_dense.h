@@ -1035,7 +1035,7 @@ QPN void co_solve_backward(const double *L_, int n, int ld, double *x_, double *
 /* Variants of this sweep that were built, measured slower (or equal) on MI355X and removed from this file in round 4 -- helper
  * wave (QP_UHELP / QP_HSPLIT), rank-split panel wave (QP_PSPLIT) and rank-split table application (QP_ASPLIT / QP_APF), delayed /
  * throttled owners (QP_ODELAY / QP_OSLEEP), the knock-out timing builds (QP_KO, QP_PROBE_NO_OWNER_TABLE) -- live as a patch in
- * tools/variants/ (tools/build_variant.sh applies it); DESIGN.md section 7 keeps their numbers. */
+ * tools/variants/ (tools/evidence/build_variant.sh applies it); DESIGN.md section 7 keeps their numbers. */
 #define QP_CWG(U, buf, col) (U).cwg[buf][col]
 template <int K> struct UpdownCfg {
   static constexpr int NB = (K > 16) ? QP_UNBS32 : QP_UNBS; /* columns per block = per phase */

@@ -144,7 +144,7 @@ static __device__ __forceinline__ int qp_fresh_lane_() {
 /* A wave-uniform "true" the compiler cannot see through: `if (QP_CALL_BLOCK()) callee(...)` gives the call a basic block
  * of its own behind a scalar branch.  Why: ROCm 7.2's register allocator saves caller-saved VGPRs around a call with
  * copies at the top of the block that holds the call; when that block starts with the `s_or_b64 exec` closing a divergent
- * loop, the copies land AHEAD of it and run with the loop's lanes still switched off (tools/scan_exec_prologue.py finds
+ * loop, the copies land AHEAD of it and run with the loop's lanes still switched off (tools/evidence/scan_exec_prologue.py finds
  * them in the -save-temps assembly; __graft_entry__.build() runs it over the shipped library). */
 static __device__ __forceinline__ int qp_opaque_true_() {
   int one;

@@ -50,8 +50,10 @@ static_assert(sizeof(UpdownLds<1, 8>) <= 38912 && sizeof(FactorLds) + sizeof(Fac
 #define QP_LDS_SMALL 38912
 #define QP_TWO_INSTANCES 1
 
-static std::string g_rt_err;
-static int g_rt_sticky = 0; /* a failed copy/memset is remembered until the API call returns (api_ok() in qpalm_capi.inc) */
+/* per host thread: qpg_batch_create allocates the device arena on a thread of its own, whose failure reaches the caller through
+ * qpg_batch::arena_rc -- it must not write (or clear) the error state of whatever API call the caller's thread is in */
+static thread_local std::string g_rt_err;
+static thread_local int g_rt_sticky = 0; /* a failed copy/memset is remembered until the API call returns (api_ok() in qpalm_capi.inc) */
 static int rt_check(hipError_t e, const char *what) {
   if (e == hipSuccess) return 0;
   g_rt_err = std::string(what) + ": " + hipGetErrorString(e);

@@ -264,7 +264,7 @@ QPD void qp_place_panel_wave(const qpg_view &V, QpShared &S) {
     const int arrival = atomicAdd(V.queue + 64 + key, 1);
     int pw = 0;
     /* The hardware deals the wavefronts of a workgroup to the SIMDs in the order 0, 2, 1, 3, 0, 2, 1, 3 (rotated by where
-     * it starts; measured, tools/placement.py), so the wavefront after the panel wave -- the helper wave of the update sweep
+     * it starts; measured, tools/scratch/placement.py), so the wavefront after the panel wave -- the helper wave of the update sweep
      * when that variant is built, second in priority -- sits two SIMDs further.  Panel waves of the two workgroups of a CU
      * on SIMDs 0 and 1 keep all four serial wavefronts on SIMDs of their own. */
     const int target = (QP_NW >= 8) ? (arrival & 1) : (arrival & 3);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_updown(qpg_view V, int
   else co_updown_block<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, J, r0, kk, n_up, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
-/* Diagnostic (tools/sweep_probe.py): every resident workgroup factorises Q + I/gamma of its QP and then applies `reps` times a
+/* Diagnostic (tools/evidence/sweep_probe.py): every resident workgroup factorises Q + I/gamma of its QP and then applies `reps` times a
  * rank-`nranks` update followed by the downdate with the same rows of A (constraints 0 .. nranks-1), so that variants of the
  * update sweep can be timed under the contention of a full chip without running the solver around them.  The phase timers of
  * the sweeps (QPGStats.ms_dbg) are left in the QP's scalars.  Not part of the solver path. */
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_sweep_probe(qpg_view V, i
 
 /* HBM yardsticks quoted by bench.py next to the 8 TB/s spec figure ("measure the attainable
  * ceiling on the box"): a copy (read + write; every workgroup streams contiguous 32 KB pieces, eight 16-byte loads in
- * flight per lane -- the best of the forms in tools/copybench.hip, ~5.4 TB/s) and a read-only stream (~6.5 TB/s). */
+ * flight per lane -- the best of the forms in tools/evidence/copybench.hip, ~5.4 TB/s) and a read-only stream (~6.5 TB/s). */
 __global__ __launch_bounds__(256) void k_hbm_copy(const double *__restrict__ src, double *__restrict__ dst, size_t npairs) {
 #ifdef QPALM_EMU
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) { dst[2 * i] = src[2 * i]; dst[2 * i + 1] = src[2 * i + 1]; }

@@ -84,7 +84,7 @@ typedef struct {
 /* view of one batch in device memory; passed by value to the kernels */
 typedef struct {
   int32_t B, n, m, ld, nnzA, nnzQ, nnzQf, nslots, lds_bytes, update_rank_threshold, ls_stride, wst_stride, place_panel_wave, narrow_rows;
-  int32_t offload, sweep_ranks; /* sweep_ranks: most ranks one sweep of the rank update applies (16, or 32 = the multi-pass form of dense_updown, the default).  coop mode: 1 = dev_solve suspends at its linear-algebra site for factorisations and Newton solves, 2 = for rank updates too */
+  int32_t offload, sweep_ranks; /* sweep_ranks: most ranks one sweep of the rank update applies (16, the default, or 32 = the multi-pass form of dense_updown: bit-identical factors, measured slower).  coop mode: 1 = dev_solve suspends at its linear-algebra site for factorisations and Newton solves, 2 = for rank updates too */
   int32_t kkt_compact, kkt_pad; /* 1: KKT mode factorises the variables + ACTIVE constraints only and spreads the factor out (qpalm_kkt.h) */
   int32_t kkt, nfac; /* kkt != 0: FACTORIZE_KKT, the factor slots hold the (n+m) x (n+m) KKT panel; nfac = rows of a factor slot
                         (n, or n + m in KKT mode); ld = its leading dimension */

@@ -1,4 +1,4 @@
-"""Randomised parity cases (TEST INFRASTRUCTURE, used by tools/fuzz_parity.py and tests/test_fuzz_seeds.py): small random QPs with
+"""Randomised parity cases (TEST INFRASTRUCTURE, used by tools/evidence/fuzz_parity.py and tests/test_fuzz_seeds.py): small random QPs with
 random shapes, bound patterns, settings (scaling, proximal, sigma, gamma, dual termination, KKT / Schur, inner_max_iter,
 max_iter) and warm starts.  `cases(seed, count, n_lo, n_hi)` yields (index, problem, settings, warm_start) in a fixed order:
 case k of a seed is always the same problem (the draws of a case do not depend on any solve)."""

@@ -1,4 +1,4 @@
-"""The build gate against the ROCm 7.2 register-allocator fault ("compiler fault"): qpalm_amd/asm_gate.py (CLI: tools/scan_exec_prologue.py)
+"""The build gate against the ROCm 7.2 register-allocator fault ("compiler fault"): qpalm_amd/asm_gate.py (CLI: tools/evidence/scan_exec_prologue.py)
 must flag a plain VGPR-to-VGPR copy that sits between a block label and the `s_or_b64 exec, exec, ...` of that block, and must not
 flag computed values there (phis of the lanes that were active) nor copies behind the exec restore."""
 import importlib.util

@@ -1,4 +1,4 @@
-"""Randomised parity campaigns as tests (cases: tests/fuzz_cases.py; the same streams tools/fuzz_parity.py walks).
+"""Randomised parity campaigns as tests (cases: tests/fuzz_cases.py; the same streams tools/evidence/fuzz_parity.py walks).
 
 The assertion, for EVERY case of every campaign (tests/fuzz_cases.py: judge_case):
   * status AND iteration count equal the oracle's, x within 1e-8, y within max(1e-8, 100 sigma dx) where sigma is the largest penalty the

@@ -107,7 +107,7 @@ def test_reference_status_paths(ctx, golden):
 def test_dual_objective_at_size(ctx, shape):
     """compute_dual_objective (iteration.c:272-299) on QPs that fill several wavefronts and both kernel instances, with
     and without scaling: status, iteration counts and the dual objective itself against the oracle.  (Round 3: the value
-    was wrong on the hardware from about 70 variables on -- a compiler fault, tools/scan_exec_prologue.py -- while every
+    was wrong on the hardware from about 70 variables on -- a compiler fault, tools/evidence/scan_exec_prologue.py -- while every
     small reference fixture passed.)"""
     n, m = shape
     if ctx.kind == "emu" and n > 100:

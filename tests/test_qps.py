@@ -273,11 +273,14 @@ def test_fixed_qps_files_on_gfx950():
         assert np.array_equal(one[path][0], two[path][0]) and np.array_equal(one[path][1], two[path][1])   # batch composition does not change results
 
 
-def test_qps_files_as_one_mixed_size_batch(ctx, host_lib):
+def test_qps_files_as_one_mixed_size_batch(ctx, request):
     """The fixtures (n = 2, 5, 6; m = 4, 8, 12) plus two random QPs of other sizes in ONE batch (members keep their own
-    dimensions on the device), against the oracle on each file's data; QPTEST's published optimum as a known answer."""
+    dimensions on the device), against the oracle on each file's data; QPTEST's published optimum as a known answer.
+    The files are read by the host library of the backend under test: the shipped libqpalm.so on the hardware ([hip]), the
+    emulator-linked build of the same C source on the CPU ([emu])."""
+    reader = None if ctx.kind == "hip" else request.getfixturevalue("host_lib")
     paths = sorted(glob.glob(os.path.join(QDIR, "*.qps")))
-    probs = [read_qps(p, host_lib) for p in paths] + [random_qp(12, 20, seed=3, density_A=0.3, density_M=0.2), random_qp(7, 30, seed=4, density_A=0.3, density_M=0.3)]
+    probs = [read_qps(p, reader) for p in paths] + [random_qp(12, 20, seed=3, density_A=0.3, density_M=0.2), random_qp(7, 30, seed=4, density_A=0.3, density_M=0.3)]
     st = dict(eps_abs=1e-7, eps_rel=1e-7, verbose=0)
     bt = QpalmBatch(ctx, probs, ctx.default_settings(**st))
     assert (bt.n, bt.m) == (12, 30)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # an experimental build of the HIP library next to the shipped one:
-#   tools/build_variant.sh [--patch file.patch] [--ipra] <name> "<extra -D flags>"
-# -> qpalm_amd/lib/libqpalm_gfx950_<name>.so (git-ignored, travels to the GPU box; run with bench.py --lib or tools/ab_multi.sh)
+#   tools/evidence/build_variant.sh [--patch file.patch] [--ipra] <name> "<extra -D flags>"
+# -> qpalm_amd/lib/libqpalm_gfx950_<name>.so (git-ignored, travels to the GPU box; run with bench.py --lib or tools/scratch/ab_multi.sh)
 # --patch: the sources are copied to a scratch directory and the patch (tools/variants/*.patch) is applied there.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 src=qpalm_amd/csrc
 patch=""
 ipra="-mllvm -enable-ipra=0"

@@ -12,7 +12,7 @@ import torch
 
 torch.cuda.init()
 os.environ.setdefault("QPALM_COOP_PROFILE", "1")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from qpalm_amd.problems import random_qp  # noqa: E402
 from qpalm_amd.solver import Context, QpalmBatch  # noqa: E402
 

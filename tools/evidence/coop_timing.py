@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 torch.cuda.init()
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from qpalm_amd.problems import random_qp  # noqa: E402
 from qpalm_amd.solver import Context, QpalmBatch  # noqa: E402
 

@@ -1,4 +1,4 @@
-// HBM copy yardstick variants (which form reaches the ~6.3 TB/s the guide quotes): hipcc --offload-arch=gfx950 -O3 tools/copybench.hip -o /tmp/cb && /tmp/cb
+// HBM copy yardstick variants (which form reaches the ~6.3 TB/s the guide quotes): hipcc --offload-arch=gfx950 -O3 tools/evidence/copybench.hip -o /tmp/cb && /tmp/cb
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d2 __attribute__((ext_vector_type(2)));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prints the figures of an evidence set (profiles/<round>/final/, written by tools/round_artifacts.sh) that DESIGN.md section 4 quotes,
+"""Prints the figures of an evidence set (profiles/<round>/final/, written by tools/evidence/round_artifacts.sh) that DESIGN.md section 4 quotes,
 so that the table there is copied from the files and not retyped.  usage: evidence_table.py [profiles/r04/final]"""
 import csv
 import json
@@ -7,7 +7,7 @@ import os
 import re
 import sys
 
-d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04", "final")
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r04", "final")
 J = lambda f: json.load(open(os.path.join(d, f)))
 b = J("bench_default.json")
 r, st = b["roofline"], b["solve_stats"]

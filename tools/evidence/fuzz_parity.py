@@ -1,12 +1,12 @@
 """Randomised parity fuzzing (cases: tests/fuzz_cases.py), the engine against the oracle, judged by the rule of tests/test_fuzz_seeds.py
 (judge_case: status and iteration count exact, x to 1e-8, y to max(1e-8, 100 sigma dx) -- unless the oracle's own outcome
-depends on its floating-point contraction, then status among the variants' and objectives to 10 x eps).  TEST TOOL (uses oracle/): python tools/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi] [key=value ...]
+depends on its floating-point contraction, then status among the variants' and objectives to 10 x eps).  TEST TOOL (uses oracle/): python tools/evidence/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi] [key=value ...]
 (key=value pairs force settings, e.g. factorization_method=0 sigma_init=1e3)."""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from qpalm_amd.solver import Context  # noqa: E402
 from tests.fuzz_cases import cases, judge_case, run_case  # noqa: E402

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box comparison of HIP builds with the phase split: tools/gpu_ab.sh <batch> <name> [<name> ...]
+# same-box comparison of HIP builds with the phase split: tools/evidence/gpu_ab.sh <batch> <name> [<name> ...]
 # (name = suffix of qpalm_amd/lib/libqpalm_gfx950_<name>.so; "cur" = the shipped build)   -> gpurun_out/gab_<name>.json, gpurun_out/gab.txt
 mkdir -p gpurun_out
 B=$1; shift

@@ -1,4 +1,4 @@
-// Latency microbenchmarks for gfx950 (single wavefront unless noted). hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o /tmp/mb && /tmp/mb
+// Latency microbenchmarks for gfx950 (single wavefront unless noted). hipcc --offload-arch=gfx950 -O3 tools/evidence/microbench.hip -o /tmp/mb && /tmp/mb
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round evidence, run on the GPU box:  bash tools/round_artifacts.sh [round]   (outputs under gpurun_out/<round>/final/)
+# Round evidence, run on the GPU box:  bash tools/evidence/round_artifacts.sh [round]   (outputs under gpurun_out/<round>/final/)
 # Copies to profiles/<round>/ are made by hand from the merged gpurun_out/.  Every step has its own timeout.
-R=${1:-r04}
+R=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/$R/final
 mkdir -p $OUT
@@ -20,7 +20,7 @@ cd $OUT
 find kt -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_default.csv \;
 find ktm -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_mpc160.csv \;
 find ktk -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_mpc160_kkt.csv \;
-python3 $REPO/tools/pmc_summary.py $OUT $REPO > $OUT/k_solve_pmc_traffic.json
+python3 $REPO/tools/evidence/pmc_summary.py $OUT $REPO > $OUT/k_solve_pmc_traffic.json
 rm -rf kt ktm ktk pmc_fetch pmc_write pmc_sq
 cd $REPO
 # the reported line: same build, same box, traffic from the passes above (bench.py checks the source and library hashes recorded in the summary)
@@ -29,10 +29,17 @@ timeout 600 python bench.py --batch 512 --no-cpu --no-mpc > $OUT/bench_b512.json
 timeout 600 python bench.py --workload mpc-160 --steps 5 > $OUT/bench_mpc160.json 2>> $OUT/bench_default.err
 timeout 600 python bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt.json 2>> $OUT/bench_default.err
 timeout 600 python bench.py --sweep-ranks 32 --no-cpu --no-mpc > $OUT/bench_sweep_ranks_32.json 2>> $OUT/bench_default.err
-bash tools/phase_traffic.sh $R/final/phase_traffic > $OUT/phase_traffic.log 2>&1
-timeout 300 python tools/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_probe.txt 2>> $OUT/bench_default.err
-timeout 300 python tools/setup_timing.py 8192 > $OUT/setup_timing.txt 2>&1
-timeout 600 python tools/coop_timing.py 512 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
-timeout 300 tools/sload_coherence_test > $OUT/sload_coherence.txt 2>&1
-timeout 200 tools/host_alloc_probe > $OUT/host_alloc_probe.txt 2>&1
+bash tools/evidence/phase_traffic.sh $R/final/phase_traffic > $OUT/phase_traffic.log 2>&1
+timeout 300 python tools/evidence/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_probe.txt 2>> $OUT/bench_default.err
+timeout 300 python tools/evidence/setup_timing.py 8192 > $OUT/setup_timing.txt 2>&1
+timeout 600 python tools/evidence/coop_timing.py 512 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
+# config 5 as written (n = 5000 nonconvex): wall time and the coop profile of one solve, every round
+QPALM_COOP_PROFILE=1 timeout 900 python -m pytest tests/test_coop.py -q -m gpu -k config5 -s > $OUT/config5.txt 2>&1
+# batch sizes between "one QP" and "the chip is full" (missing #2)
+mkdir -p $REPO/gpurun_out/$R/batch
+for b in 16 64 128 256; do timeout 300 python bench.py --batch $b --steps 3 --warmup 1 --no-cpu --no-mpc > $REPO/gpurun_out/$R/batch/bench_b$b.json 2>> $OUT/bench_default.err; done
+# the sparse factor at size
+timeout 900 python -m pytest tests/test_sparse_factor.py -q -m gpu -s > $OUT/sparse_factor_at_size.txt 2>&1
+timeout 300 tools/evidence/sload_coherence_test > $OUT/sload_coherence.txt 2>&1
+timeout 200 tools/evidence/host_alloc_probe > $OUT/host_alloc_probe.txt 2>&1
 ls -la $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of two HIP builds on the headline workload: tools/ab_lib.sh <other lib> [bench args]
+# same-box A/B of two HIP builds on the headline workload: tools/scratch/ab_lib.sh <other lib> [bench args]
 mkdir -p gpurun_out
 OTHER=$1; shift
 for rep in 1 2; do

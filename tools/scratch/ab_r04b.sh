@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B (run on the GPU box): tools/ab_r04b.sh tag "name:bench args" ...   name = cur or the suffix of libqpalm_gfx950_<name>.so
+# same-box A/B (run on the GPU box): tools/scratch/ab_r04b.sh tag "name:bench args" ...   name = cur or the suffix of libqpalm_gfx950_<name>.so
 tag=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $REPO/gpurun_out/$tag

@@ -1,4 +1,4 @@
-"""One large QP on the GPU (BASELINE.json config 5 shape): python tools/big_gpu.py n m [nonconvex] -> timings, KKT residuals"""
+"""One large QP on the GPU (BASELINE.json config 5 shape): python tools/scratch/big_gpu.py n m [nonconvex] -> timings, KKT residuals"""
 import sys, time
 import numpy as np
 import scipy.sparse as sp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box comparison of build variants: tools/variants.sh "name:extra bench args" ...   (name = suffix of qpalm_amd/lib/libqpalm_gfx950_<name>.so, cur = the shipped build)
+# same-box comparison of build variants: tools/scratch/variants.sh "name:extra bench args" ...   (name = suffix of qpalm_amd/lib/libqpalm_gfx950_<name>.so, cur = the shipped build)
 mkdir -p gpurun_out
 for v in "$@"; do
   name=${v%%:*}; args=${v#*:}
