@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--kkt-compact", type=int, default=-1, help="KKT mode: 0 = factorise the whole (n+m) panel with its unit rows (A/B; default: the active rows only)")
     ap.add_argument("--ld-align", type=int, default=0, help="leading dimension of the factor panels rounded up to this many doubles (A/B; 0: library default = 16)")
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
+    ap.add_argument("--coop", type=int, default=-2, help="coop mode (several workgroups per QP, host-chained kernels): 1 force, 0 never, -1 automatic (default: the library's setting)")
+    ap.add_argument("--coop-max-batch", type=int, default=0, help="largest batch the automatic choice runs in coop mode (0: library default)")
     ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/scratch/ab.sh)")
     ap.add_argument("--traffic-json", default=None,
                     help="PMC summary written by tools/evidence/round_artifacts.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -361,6 +363,10 @@ def worker(args):
         ctx.set_option("ld_align", args.ld_align)
     if args.sweep_ranks:
         ctx.set_option("sweep_ranks", args.sweep_ranks)
+    if args.coop > -2:
+        ctx.set_option("coop", args.coop)
+    if args.coop_max_batch:
+        ctx.set_option("coop_max_batch", args.coop_max_batch)
     if args.kkt_compact >= 0:
         ctx.set_option("kkt_compact", args.kkt_compact)
     if not args.small_workgroups:

@@ -90,6 +90,7 @@ struct oq_workspace {
    * an exact zero), so the dense mode pins it: tests/test_sparse_factor.py compares the two bit for bit.  In this mode every change
    * of the active set or of sigma refactorises (no rank updates), which is what the engine's sparse factor does. */
   int sparse_mode;
+  oq_int sp_nlev;                                   /* height of the elimination tree (levels) */
   oq_int *sp_Lp, *sp_Li, *sp_Rp, *sp_Rk, *sp_Rpos; /* pattern of L by columns (strict lower, rows ascending) and by rows (columns ascending) */
   oq_float *sp_Lx, *sp_D, *sp_y;                    /* values on that pattern, pivots, dense work vector (zero outside of use) */
   /* settings / solution / info */
@@ -897,6 +898,15 @@ static void sparse_analyze(oq_workspace *w) {
   for (oq_int i = 0; i < n; i++) { Rp[i + 1] += Rp[i]; cur[i] = Rp[i]; }
   for (oq_int k = 0; k < n; k++)
     for (oq_int e = Lp[k]; e < Lp[k + 1]; e++) { oq_int dst = cur[Li[e]]++; Rk[dst] = k; Rpos[dst] = e; }
+  { /* height of the elimination tree: parent(j) = first row index of column j (children have smaller indices than their parents) */
+    oq_int *lev = izalloc((size_t)n), nlev = 0;
+    for (oq_int j = 0; j < n; j++) {
+      if (Lp[j + 1] > Lp[j]) { oq_int pj = Li[Lp[j]]; if (lev[pj] < lev[j] + 1) lev[pj] = lev[j] + 1; }
+      if (lev[j] + 1 > nlev) nlev = lev[j] + 1;
+    }
+    w->sp_nlev = nlev;
+    free(lev);
+  }
   free(mark); free(head); free(next); free(col); free(cur); sp_free(&T);
   w->sp_Lp = Lp; w->sp_Li = Li; w->sp_Rp = Rp; w->sp_Rk = Rk; w->sp_Rpos = Rpos;
   w->sp_Lx = zalloc(nz); w->sp_D = zalloc((size_t)n); w->sp_y = zalloc((size_t)n);
@@ -949,6 +959,35 @@ static void sparse_factor(oq_workspace *w, int with_AtSA, int add_beta, oq_float
     D[k] = dk;
   }
 }
+/* oq_dense_ldl_rank1 on the compressed columns: the entries of a row of A form a clique of H, so the nonzeros of the vector -- those
+ * it starts with and those it acquires -- lie on ONE path of the elimination tree, from the row's first column to the root; the dense
+ * loop's columns off that path have w_j = 0 there (they only see d_j <- (d_j alpha) / alpha, which this form leaves out, as CHOLMOD's
+ * updown does) */
+static void sparse_rank1(oq_workspace *w, oq_int t, int update) {
+  const oq_sparse *F = &w->At_sqrt_sigma;
+  if (F->p[t + 1] <= F->p[t]) return;
+  oq_float *v = w->sp_y, alpha = 1.0;
+  for (oq_int k = F->p[t]; k < F->p[t + 1]; k++) v[F->i[k]] = F->x[k];
+  oq_int j = F->i[F->p[t]];
+  while (j >= 0) {
+    oq_float wj = v[j], dj = w->sp_D[j], a, gam;
+    if (update) { a = alpha + (wj * wj) / dj; dj *= a; gam = -wj / dj; }
+    else        { a = alpha - (wj * wj) / dj; dj *= a; gam =  wj / dj; }
+    dj /= alpha;
+    alpha = a;
+    w->sp_D[j] = dj;
+    for (oq_int e = w->sp_Lp[j]; e < w->sp_Lp[j + 1]; e++) {
+      oq_int i = w->sp_Li[e];
+      oq_float wi = v[i] - wj * w->sp_Lx[e];
+      v[i] = wi;
+      w->sp_Lx[e] -= gam * wi;
+    }
+    v[j] = 0;
+    j = (w->sp_Lp[j + 1] > w->sp_Lp[j]) ? w->sp_Li[w->sp_Lp[j]] : -1;
+  }
+}
+/* the engine's rule (qpalm_sparse.h: sp_update_pays): walking nchange paths of at most nlev columns against refactorising n columns */
+static int sparse_update_pays(const oq_workspace *w, oq_int nchange) { return w->sparse_mode == 1 && (long long)nchange * (long long)w->sp_nlev * 2 < (long long)w->n; }
 static void sparse_solve(oq_workspace *w, oq_float *b) { /* oq_dense_ldl_solve on the compressed columns */
   oq_int n = w->n;
   for (oq_int j = 0; j < n; j++) { oq_float yj = b[j]; for (oq_int e = w->sp_Lp[j]; e < w->sp_Lp[j + 1]; e++) b[w->sp_Li[e]] -= w->sp_Lx[e] * yj; }
@@ -1025,6 +1064,7 @@ void oq_ldlcholQAtsigmaA(oq_workspace *w) { /* solver_interface.c:372-405 */
 static void updown_columns(oq_workspace *w, const oq_int *cols, oq_int ncols, int update) {
   /* submatrix(At_sqrt_sigma, :, cols) then updown(update, C, L) (solver_interface.c:415-421,433-439) */
   oq_int n = w->n;
+  if (w->sparse_mode) { w->n_updown_calls++; for (oq_int c = 0; c < ncols; c++) { sparse_rank1(w, cols[c], update); w->n_rank1++; } return; }
   const oq_sparse *F = &w->At_sqrt_sigma;
   w->n_updown_calls++;
   for (oq_int c = 0; c < ncols; c++) {
@@ -1249,7 +1289,8 @@ void oq_newton_set_direction(oq_workspace *w) { /* newton.c:17-120 */
   }
   if ((w->reset_newton && w->nb_active) ||
       (w->nb_enter + w->nb_leave) > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), st->max_rank_update) ||
-      (w->sparse_mode && w->nb_active && (w->nb_enter + w->nb_leave) > 0)) { /* (sparse mode: a changed active set refactorises) */
+      (w->sparse_mode && w->nb_active && (w->nb_enter + w->nb_leave) > 0 && !(w->sp_Lp && sparse_update_pays(w, w->nb_enter + w->nb_leave)))) {
+    /* (sparse mode: a changed active set refactorises unless the elimination tree is bushy enough for path updates to be cheaper) */
     oq_ldlcholQAtsigmaA(w); w->n_refactor++; w->last_fact = 1;
   } else if (w->nb_active) {
     w->last_fact = 0;
@@ -1743,7 +1784,8 @@ void oq_set_scalar(oq_workspace *w, const char *name, oq_float v) {
   else if (!strcmp(name, "tau")) w->tau = v;
   else if (!strcmp(name, "proximal")) w->settings.proximal = (oq_int)v;
   else if (!strcmp(name, "reset_newton")) w->reset_newton = (int)v;
-  else if (!strcmp(name, "sparse_mode")) w->sparse_mode = (v != 0) && !w->kkt_mode && !w->settings.enable_dual_termination; /* before the first solve */
+  else if (!strcmp(name, "sparse_mode")) w->sparse_mode = (v != 0 && !w->kkt_mode && !w->settings.enable_dual_termination) ? (int)v : 0; /* before the first solve; 1 = path
+                                                         updates where they pay (the engine's rule), 2 = every change refactorises (what pins the mode against the dense one) */
   else if (!strcmp(name, "eps_abs_in")) w->eps_abs_in = v;
   else if (!strcmp(name, "eps_rel_in")) w->eps_rel_in = v;
   else if (!strcmp(name, "nb_sigma_changed")) w->nb_sigma_changed = (oq_int)v; /* op-level tests of ldlupdate_sigma_changed */

@@ -309,8 +309,9 @@ QPD void spmv_rows(int nrows, const int *__restrict__ ptr, const int *__restrict
       pn1[u] = valid ? ptr[r + 1] : 0;
     }
   };
-  fetch_ptrs(0);
+  if (QP_SPMV_PREFETCH) fetch_ptrs(0);
   for (int r0 = 0; r0 < nrows; r0 += U * RG) {
+    if (!QP_SPMV_PREFETCH) fetch_ptrs(r0);
     int k[U], k1[U];
     double acc[U];
 #pragma unroll

@@ -129,6 +129,21 @@ static void rt_copy_wait(int k) {
  * state is per host thread: while one thread records a coop launch chain, launches of another thread (another batch / context) keep
  * going to the null stream instead of being recorded into the wrong graph. */
 static thread_local hipStream_t g_rt_stream = 0, g_rt_capture_stream = 0;
+/* Side streams for the coop launch chains of DIFFERENT QPs (round 5: batches between "a few" and "the chip is full"): the chains of the
+ * members of one round are independent of each other, so each goes to its own stream and the hardware overlaps them.  The streams are
+ * ordinary (blocking) streams: they synchronise implicitly with the null stream, on which the iteration kernel before and after them
+ * and the scalar read-back run -- no events needed. */
+#define RT_SIDE_STREAMS 32
+static thread_local hipStream_t g_rt_side[RT_SIDE_STREAMS] = {0};
+static thread_local hipStream_t g_rt_user_stream = 0; /* where plain launches and graph replays go while no capture is active */
+static void rt_use_stream(int k) {
+  if (k < 0) { g_rt_user_stream = 0; g_rt_stream = 0; return; }
+  k %= RT_SIDE_STREAMS;
+  if (!g_rt_side[k] && hipStreamCreate(&g_rt_side[k]) != hipSuccess) { g_rt_side[k] = 0; (void)hipGetLastError(); }
+  g_rt_user_stream = g_rt_side[k];
+  g_rt_stream = g_rt_user_stream;
+}
+#define RT_USE_STREAM(k) rt_use_stream(k)
 #define RT_LAUNCH(kernel, grid, block, shmem, ...)                                         \
   do {                                                                                      \
     rt_allow_lds(kernel, (shmem));                                                          \
@@ -146,7 +161,7 @@ static int rt_graph_begin() {
 }
 static int rt_graph_end(rt_graph_t *exec) {
   hipGraph_t graph = nullptr;
-  g_rt_stream = 0;
+  g_rt_stream = g_rt_user_stream;
   if (hipStreamEndCapture(g_rt_capture_stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return 1; }
   const hipError_t e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
@@ -155,7 +170,7 @@ static int rt_graph_end(rt_graph_t *exec) {
 }
 #define RT_GRAPH_BEGIN() rt_graph_begin()
 #define RT_GRAPH_END(pexec) rt_graph_end(pexec)
-#define RT_GRAPH_LAUNCH(exec) rt_check(hipGraphLaunch((exec), 0), "hipGraphLaunch")
+#define RT_GRAPH_LAUNCH(exec) rt_check(hipGraphLaunch((exec), g_rt_user_stream), "hipGraphLaunch")
 #define RT_GRAPH_FREE(exec) (void)hipGraphExecDestroy(exec)
 #define RT_TIMED_LAUNCH(ms, kernel, grid, block, shmem, ...)                                \
   do {                                                                                      \

@@ -919,11 +919,13 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     const long long t0 = QP_CLOCK();
     double gersh_ub = 0.0;
     if constexpr (SPARSE) {
-      /* sparse factor (qpalm_sparse.h): every change of the matrix refactorises -- no rank updates -- and a change of sigma marks
-       * the factor stale, as the reference does under FACTORIZE_KKT (iteration.c:135-144) */
+      /* sparse factor (qpalm_sparse.h): rows entering / leaving the active set are rank-1 updates along their elimination-tree
+       * paths where that pays, a refactorisation otherwise; a change of sigma marks the factor stale (dev_update_sigma_pre), as the
+       * reference does under FACTORIZE_KKT (iteration.c:135-144) */
       const SpArrays SP = sp_arrays(V, b, slot, Dg);
-      if (la == 2) { la = 1; action = 1; }
-      if (la == 1 || la == 3) sp_factor(V, b, n, SP, la == 1, prox != 0, gam);
+      if (la == 2 && !sp_update_pays(nchange, SP.nlev, n)) { la = 1; action = 1; } /* a chain-like tree: refactorising is cheaper than walking it per row */
+      if (la == 2) sp_updown(V, b, n, SP, a.enter(), I.s.nb_enter, a.leave(), I.s.nb_leave);
+      else if (la == 1 || la == 3) sp_factor(V, b, n, SP, la == 1, prox != 0, gam);
       else if (la == 5) gersh_ub = sp_gershgorin(V, b, n, SP, I.S);
     } else
     if (resume) {

@@ -18,8 +18,9 @@
  *  - Triangular solves in place on the right-hand side in HBM: forward by rows (x_j = b_j - sum_k l_jk x_k, k ascending: the
  *    order of the column-oriented loop of cholmod_solve), levels ascending, one thread per row; D; backward by columns, levels
  *    descending.
- *  - Changes of the active set or of sigma REFACTORISE (the reference's own behaviour under FACTORIZE_KKT, iteration.c:135-144, and
- *    for more than max_rank_update changes): rank updates along the elimination-tree paths are not built.
+ *  - Rows that enter or leave the active set: rank-1 updates / downdates along the row's path of the elimination tree (sp_updown) when
+ *    the tree is bushy enough for that to be cheaper than a refactorisation (sp_update_pays), else a refactorisation.  Changes of
+ *    sigma refactorise (the reference's own behaviour under FACTORIZE_KKT, iteration.c:135-144).
  * One workgroup per QP like the dense engine: batches of sparse QPs fill the chip; a single large sparse QP runs at the latency of
  * its level chain (a band matrix has n levels).  DESIGN.md section 2.
  */
@@ -146,6 +147,55 @@ QPN double sp_gershgorin(const qpg_view &V, int b, const int n, const SpArrays &
   double vm[1] = {gmax}, vs[1] = {0.0};
   block_reduce<1, 0>(Sh, vm, vs);
   return vm[0];
+}
+
+/* Rank-1 updates (rows entering the active set) and downdates (rows leaving it) of the sparse factor, one row of A at a time:
+ * CHOLMOD's updown semantics (solver_interface.c:407-441) on a FIXED pattern -- L's pattern was computed for all rows of A, so an
+ * entering row never adds structure.  The entries of a row of A form a clique of H, hence lie on ONE path of the elimination tree:
+ * the update walks that path from the row's first column to the root (parent(j) = first row index of column j's pattern), wavefront 0
+ * alone, lanes over the entries of the column; the work vector is consumed (zeroed) on the way.  Per column Davis & Hager's method C1 in
+ * the oracle's form (oq_dense_ldl_rank1: a = alpha +- w_j^2 / d_j, d_j <- d_j a / alpha, gamma = -+ w_j / (d_j a)), per entry
+ * w_i <- w_i - w_j l_ij, l_ij <- l_ij - gamma w_i.  Columns off the path are not touched.  Cost: one chain step (a few dependent HBM
+ * round trips) per path column -- cheap on bushy trees (block structure), hopeless on a chain (band matrix): sp_update_pays decides. */
+QPD bool sp_update_pays(int nchange, int nlev, int n) { return (long long)nchange * (long long)nlev * 2 < (long long)n; }
+QPN void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S, const int *up, int n_up, const int *dn, int n_dn) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
+  const double *Atss = V.Atss + (size_t)b * V.nnzA;
+  double *w = S.wv; /* wavefront 0's work vector */
+  __syncthreads();
+  if (wid == 0) {
+    for (int c = 0; c < n_up + n_dn; c++) {
+      const bool update = c < n_up;
+      const int t = update ? up[c] : dn[c - n_up];
+      const int q0 = Atp[t], q1 = Atp[t + 1];
+      if (q1 <= q0) continue;
+      for (int q = q0 + lane; q < q1; q += 64) w[Ati[q]] = Atss[q];
+      QP_WAVE_SYNC();
+      double alpha = 1.0;
+      int j = Ati[q0]; /* the row's first column (columns ascending) */
+      while (j >= 0) {
+        const int e0 = S.Lp[j], e1 = S.Lp[j + 1];
+        const double wj = w[j];
+        double dj = S.Dg[j], a, gam;
+        QP_WAVE_SYNC(); /* every lane has read w_j and d_j before lane 0 overwrites them below */
+        if (update) { a = alpha + (wj * wj) / dj; dj *= a; gam = -wj / dj; }
+        else        { a = alpha - (wj * wj) / dj; dj *= a; gam =  wj / dj; }
+        dj /= alpha;
+        alpha = a;
+        for (int e = e0 + lane; e < e1; e += 64) {
+          const int i = S.Li[e];
+          const double wi = w[i] - wj * S.Lx[e];
+          w[i] = wi;
+          S.Lx[e] = S.Lx[e] - gam * wi;
+        }
+        if (lane == 0) { S.Dg[j] = dj; w[j] = 0.0; }
+        QP_WAVE_SYNC();
+        j = (e1 > e0) ? S.Li[e0] : -1;
+      }
+    }
+  }
+  __syncthreads();
 }
 
 /* x <- (L D L')^-1 x, in place in HBM */
