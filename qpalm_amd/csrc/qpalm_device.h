@@ -282,9 +282,6 @@ QPD void block_compact2(QpShared &S, int count, F0 f0, F1 f1, int *out0, int *ou
 /* y[r] = sum_k val[k] * x[idx[k]], k in [ptr[r], ptr[r+1]) -- one sub-wavefront of G lanes per
  * compressed column/row, coalesced walk of idx/val, butterfly reduce.  Used for A'*yh (CSC of A),
  * A*d (CSC of A') and Q*d (full symmetric pattern).  post(r, sum) consumes the result. */
-#ifndef QP_SPMV_PREFETCH
-#define QP_SPMV_PREFETCH 1
-#endif
 #ifndef QP_SPMV_ROWS
 #define QP_SPMV_ROWS 4 /* rows in flight per lane group; 8 spills under the 128-VGPR cap (measured slower) */
 #endif
@@ -297,30 +294,17 @@ QPD void spmv_rows(int nrows, const int *__restrict__ ptr, const int *__restrict
    * `sub` accumulates entries sub, sub+G, ... in order, then the xor tree. */
   constexpr int U = QP_SPMV_ROWS, RG = QP_T / G;
   const int sub = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-  /* the row pointers of the NEXT round are fetched while this round's entries are in flight (round 5): one dependent round trip
-   * per round instead of two (pointer -> index / value), the gather being an LDS read when the vector is staged there */
-  int pn[U], pn1[U];
-  auto fetch_ptrs = [&](const int rb) QP_ALWAYS_INLINE {
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int r = rb + grp + u * RG;
-      const bool valid = r < nrows;
-      pn[u] = valid ? ptr[r] : 0;
-      pn1[u] = valid ? ptr[r + 1] : 0;
-    }
-  };
-  if (QP_SPMV_PREFETCH) fetch_ptrs(0);
   for (int r0 = 0; r0 < nrows; r0 += U * RG) {
-    if (!QP_SPMV_PREFETCH) fetch_ptrs(r0);
     int k[U], k1[U];
     double acc[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      k[u] = (r0 + grp + u * RG < nrows) ? pn[u] + sub : 0;
-      k1[u] = pn1[u];
+      const int r = r0 + grp + u * RG;
+      const bool valid = r < nrows;
+      k[u] = valid ? ptr[r] + sub : 0;
+      k1[u] = valid ? ptr[r + 1] : 0;
       acc[u] = 0.0;
     }
-    if (QP_SPMV_PREFETCH && r0 + U * RG < nrows) fetch_ptrs(r0 + U * RG);
     while (true) {
       bool more = false;
 #pragma unroll

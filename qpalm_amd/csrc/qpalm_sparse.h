@@ -42,6 +42,11 @@ QPD SpArrays sp_arrays(const qpg_view &V, int b, int slot, double *Dg) {
   return s;
 }
 
+/* levels lev and lev + 1 both hold ONE column: the same wavefront (thread) handles both, in program order, and nobody else works */
+QPD bool sp_level_needs_barrier(const SpArrays &S, int lev) {
+  if (lev + 1 >= S.nlev) return true;
+  return (S.levptr[lev + 1] - S.levptr[lev] > 1) || (S.levptr[lev + 2] - S.levptr[lev + 1] > 1);
+}
 /* H = Q (+ A' Sigma_act A) (+ I / gamma) assembled column by column and factorised in the same pass (see the header).
  * Q_only_values: the second resident factor LD_Q of the dual objective is not supported in sparse mode (qpg_batch_create refuses). */
 QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, bool with_AtSA, bool proximal, double gamma) {
@@ -105,8 +110,10 @@ QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, boo
       if (lane == 0) { S.Dg[j] = dj; w[j] = 0.0; }
       QP_WAVE_SYNC();
     }
-    __syncthreads();
+    /* a run of one-column levels (a chain of the tree) is wavefront 0's alone: no workgroup barrier inside the run */
+    if (sp_level_needs_barrier(S, lev)) __syncthreads();
   }
+  __syncthreads();
 }
 
 /* max_j (C_jj + sum_{i != j} |C_ij|),  C = A' Sigma_act A  (gershgorin_max of nonconvex.c:185-210, used by boost_gamma): full
@@ -208,8 +215,9 @@ QPN void sp_solve(const int n, const SpArrays &S, double *x) {
       for (int r = S.Rp[j]; r < S.Rp[j + 1]; r++) v -= S.Lx[S.Rpos[r]] * x[S.Rk[r]];
       x[j] = v;
     }
-    __syncthreads();
+    if (sp_level_needs_barrier(S, lev)) __syncthreads();
   }
+  __syncthreads();
   for (int j = threadIdx.x; j < n; j += QP_T) x[j] = x[j] / S.Dg[j];
   __syncthreads();
   for (int lev = S.nlev - 1; lev >= 0; lev--) { /* backward: a column needs the rows of its pattern (ancestors: later levels) */
@@ -219,8 +227,9 @@ QPN void sp_solve(const int n, const SpArrays &S, double *x) {
       for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) v -= S.Lx[e] * x[S.Li[e]];
       x[j] = v;
     }
-    __syncthreads();
+    if (lev == 0 || sp_level_needs_barrier(S, lev - 1)) __syncthreads();
   }
+  __syncthreads();
 }
 
 #endif

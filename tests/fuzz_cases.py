@@ -69,12 +69,15 @@ def y_bound_from_dx(p, o, dx):
     return float(np.max(t) / max(1.0, float(np.max(np.abs(o.y))))) if t.size else 0.0
 
 
-def run_case(ctx, p, st, warm):
-    """the engine and the oracle on one case -> dict(status, iter (engine, oracle), x / y relative differences)"""
+def run_case(ctx, p, st, warm, oracle_sparse_mode=0):
+    """the engine and the oracle on one case -> dict(status, iter (engine, oracle), x / y relative differences)
+    oracle_sparse_mode: the oracle's storage of the Schur factor (campaign S: the engine runs with the context option sparse_factor = 1)"""
     import oracle.binding as ob
     from qpalm_amd.solver import QpalmBatch
     bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
     o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
+    if oracle_sparse_mode:
+        o.set_scalar("sparse_mode", oracle_sparse_mode)
     if warm is not None:
         bt.warm_start(warm[0][None, :], warm[1][None, :])
         o.warm_start(warm[0], warm[1])

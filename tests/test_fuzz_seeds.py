@@ -83,6 +83,40 @@ def test_fuzz_dual_termination_campaign(ctx):
     assert len(soft) <= max(1, total // 50), soft
 
 
+def test_fuzz_sparse_factor_campaign(ctx):
+    """Campaign S (round 5): the general campaign's problems on the Schur path with the SPARSE factor (context option sparse_factor = 1:
+    symbolic analysis of every random pattern, fused assemble-and-factorise, path updates where they pay) against the oracle in its
+    sparse-storage mode, which refactorises and updates by the same rule: status, iteration count, x and y as in the other campaigns."""
+    plan = [(51, 10, 2, 40)] if ctx.kind == "emu" else [(51, 300, 2, 70), (52, 60, 257, 420)]
+    force = dict(factorization_method=1, enable_dual_termination=0)
+    bad, soft, total = [], [], 0
+    ctx.set_option("sparse_factor", 1)
+    try:
+        for seed, count, n_lo, n_hi in plan:
+            for it, p, st, warm, meta in cases(seed, count, n_lo, n_hi, force):
+                r = run_case(ctx, p, st, warm, oracle_sparse_mode=1)
+                ok = r["status"][0] == r["status"][1] and r["iter"][0] == r["iter"][1]
+                if ok and r["status"][1] in (1, 2):
+                    ytol = min(1e-4, max(1e-8, 2.0 * max(1, r["iter_out"]) * r["ybound"]))
+                    ok = r["dx"] <= 1e-8 and r["dy"] <= ytol
+                if not ok:
+                    # the dense rule's escape (oracle variants, trajectories) is built for the dense oracle: a sparse-mode mismatch is
+                    # re-judged on the dense path of both, which must then be rounding-decided there
+                    ctx.set_option("sparse_factor", 0)
+                    rd = run_case(ctx, p, st, warm)
+                    okd, why, rounding = judge_case(rd, p, st, warm, 1e-8, ctx)
+                    ctx.set_option("sparse_factor", 1)
+                    if okd and rounding:
+                        soft.append((seed, it, r["status"], r["iter"], why))
+                    else:
+                        bad.append((seed, it, meta, r["status"], r["iter"], r["dx"], r["dy"]))
+                total += 1
+    finally:
+        ctx.set_option("sparse_factor", -1)
+    assert not bad, bad
+    assert len(soft) <= max(1, total // 50), soft
+
+
 def test_sigma_grown_by_one_ulp(ctx):
     """Seed 204 case 155 of round 4's fresh-seed campaign: one sigma_k grows by one unit in the last place, sqrt(mult_factor) == 1, and the
     reference's CHOLMOD branch of ldlupdate_sigma_changed would scale the zeroed row of At_sqrt_sigma back by 1/0 (solver_interface.c:

@@ -175,3 +175,64 @@ def test_sparse_factor_at_size(kind, n):
     assert o.status_val == 1 and int(info.iter) == int(o.info.iter) and int(s.n_refactor) == o.counter("n_refactor")
     assert rel(x[0], o.x) <= 1e-8 and rel(y[0], o.y) <= 1e-8
     bt.close()
+
+
+def write_free_qps(path, p, name="SPARSEQP"):
+    """a QP of qpalm_amd.problems as a free-format QPS file: every row an L row with RHS = bmax and RANGES = bmax - bmin, every variable FR
+    (the reader then appends no bound rows), QUADOBJ = the lower triangle"""
+    A = sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n))
+    Q = sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(p.n, p.n))
+    with open(path, "w") as f:
+        f.write("NAME %s\nROWS\n N obj\n" % name)
+        for i in range(p.m):
+            f.write(" L r%d\n" % i)
+        f.write("COLUMNS\n")
+        for j in range(p.n):
+            if p.q[j] != 0.0:
+                f.write(" x%d obj %r\n" % (j, float(p.q[j])))
+            for k in range(A.indptr[j], A.indptr[j + 1]):
+                f.write(" x%d r%d %r\n" % (j, A.indices[k], float(A.data[k])))
+        f.write("RHS\n")
+        for i in range(p.m):
+            f.write(" rhs r%d %r\n" % (i, float(p.bmax[i])))
+        f.write("RANGES\n")
+        for i in range(p.m):
+            f.write(" rng r%d %r\n" % (i, float(p.bmax[i] - p.bmin[i])))
+        f.write("BOUNDS\n")
+        for j in range(p.n):
+            f.write(" FR bnd x%d\n" % j)
+        f.write("QUADOBJ\n")
+        for j in range(p.n):
+            for k in range(Q.indptr[j], Q.indptr[j + 1]):
+                if Q.indices[k] >= j:
+                    f.write(" x%d x%d %r\n" % (j, Q.indices[k], float(Q.data[k])))
+        f.write("ENDATA\n")
+
+
+@pytest.mark.gpu
+def test_large_sparse_qps_files_through_the_reader(tmp_path):
+    """BASELINE.json config 4 on members the dense panel could not take: two generated QPS files with n = 12 000 and 30 000 (the large
+    Maros-Meszaros members -- LISWET, CONT-xxx, AUG3DCQP, BOYD -- have n = 10^4 .. 10^5 and > 99 % sparse Schur complements; the set itself
+    is not in the image) and a small dense-friendly one, streamed through interfaces/qps' reader (the shipped libqpalm.so) as size-bucketed
+    batches; each against the oracle (sparse storage for the large ones) on the data the reader returned."""
+    from qpalm_amd.qps import read_qps, solve_qps_files
+    from qpalm_amd.solver import Context
+    ctx = Context(0)
+    gens = [("banded12k", sparse_qp(12000, "banded", seed=31)), ("blocks30k", sparse_qp(30000, "blocks", seed=32)), ("small", sparse_qp(40, "banded", seed=33))]
+    paths = []
+    for name, p in gens:
+        path = str(tmp_path / (name + ".qps"))
+        write_free_qps(path, p, name.upper())
+        paths.append(path)
+    res = solve_qps_files(ctx, paths, ctx.default_settings(**ST))
+    for path, (name, p0) in zip(paths, gens):
+        p = read_qps(path)
+        assert (p.n, p.m) == (p0.n, p0.m) and np.array_equal(p.Ax, p0.Ax) and np.array_equal(p.Qx, p0.Qx) and np.array_equal(p.bmin, p0.bmin)
+        x, y, info = res[path]
+        o = ob.OracleQP(*p.args(), c=p.c, settings=ob.default_settings(**ST))
+        if p.n > 8192:
+            o.set_scalar("sparse_mode", 1)
+        o.solve()
+        assert int(info.status_val) == o.status_val == 1 and int(info.iter) == int(o.info.iter), (name, int(info.iter), int(o.info.iter))
+        assert rel(x, o.x) <= 1e-8 and rel(y, o.y) <= 1e-8, name
+        _kkt_check(p, x, y)
