@@ -227,7 +227,8 @@ def test_large_sparse_qps_files_through_the_reader(tmp_path):
     res = solve_qps_files(ctx, paths, ctx.default_settings(**ST))
     for path, (name, p0) in zip(paths, gens):
         p = read_qps(path)
-        assert (p.n, p.m) == (p0.n, p0.m) and np.array_equal(p.Ax, p0.Ax) and np.array_equal(p.Qx, p0.Qx) and np.array_equal(p.bmin, p0.bmin)
+        assert (p.n, p.m) == (p0.n, p0.m) and np.array_equal(p.Ax, p0.Ax) and np.array_equal(p.Qx, p0.Qx) and np.array_equal(p.bmax, p0.bmax)
+        assert np.allclose(p.bmin, p0.bmin, rtol=0, atol=1e-15)      # (bmin comes back as bmax - (bmax - bmin): RANGES on L rows)
         x, y, info = res[path]
         o = ob.OracleQP(*p.args(), c=p.c, settings=ob.default_settings(**ST))
         if p.n > 8192:

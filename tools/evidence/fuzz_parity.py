@@ -1,7 +1,7 @@
 """Randomised parity fuzzing (cases: tests/fuzz_cases.py), the engine against the oracle, judged by the rule of tests/test_fuzz_seeds.py
 (judge_case: status and iteration count exact, x to 1e-8, y to max(1e-8, 100 sigma dx) -- unless the oracle's own outcome
 depends on its floating-point contraction, then status among the variants' and objectives to 10 x eps).  TEST TOOL (uses oracle/): python tools/evidence/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi] [key=value ...]
-(key=value pairs force settings, e.g. factorization_method=0 sigma_init=1e3)."""
+(key=value pairs force settings, e.g. factorization_method=0 sigma_init=1e3; sparse=1: the engine's sparse factor against the oracle's sparse-storage mode)."""
 import os
 import sys
 import time
@@ -22,13 +22,20 @@ ctx = Context(0, lib_path=os.path.join(ROOT, 'tests', 'emu', 'libqpalm_gfx950_em
 seed = int(pos[0]) if len(pos) > 0 else 0
 N = int(pos[1]) if len(pos) > 1 else 100
 NLO, NHI = (int(pos[3]), int(pos[4])) if len(pos) > 4 else (2, 70)   # range of n (m up to 1.7 n)
+sparse = int(force.pop("sparse", 0))
+if sparse:
+    ctx.set_option("sparse_factor", 1)
+    force.update(dict(factorization_method=1, enable_dual_termination=0))
+worst_dy_ratio = 0.0   # largest dy / derived bound among the cases that needed more than 1e-8 on y
 bad = 0    # fails the rule (or an exception)
 soft = 0   # passes as a rounding-decided case
 t0 = time.time()
 for it, p, st, warm, meta in cases(seed, N, NLO, NHI, force or None):
     try:
-        r = run_case(ctx, p, st, warm)
-        ok, why, rounding = judge_case(r, p, st, warm, 1e-8, ctx)
+        r = run_case(ctx, p, st, warm, oracle_sparse_mode=1 if sparse else 0)
+        ok, why, rounding = judge_case(r, p, st, warm, 1e-8, ctx if not sparse else None)
+        if r.get("ytol_used", 0) > 1e-8 and r["dy"] > 1e-8:
+            worst_dy_ratio = max(worst_dy_ratio, r["dy"] / r["ytol_used"])
         if not ok or rounding:
             bad += 0 if ok else 1
             soft += 1 if ok else 0
@@ -38,4 +45,4 @@ for it, p, st, warm, meta in cases(seed, N, NLO, NHI, force or None):
     except Exception as e:
         bad += 1
         print("EXC", it, meta, st, repr(e)[:300])
-print("done seed", seed, "cases", N, "n", (NLO, NHI), "forced", force, "FAIL", bad, "rounding-decided", soft, "time", round(time.time() - t0, 1))
+print("done seed", seed, "cases", N, "n", (NLO, NHI), "forced", force, "FAIL", bad, "rounding-decided", soft, "largest dy / derived y bound", round(worst_dy_ratio, 3), "time", round(time.time() - t0, 1))
