@@ -237,3 +237,55 @@ def test_large_sparse_qps_files_through_the_reader(tmp_path):
         assert int(info.status_val) == o.status_val == 1 and int(info.iter) == int(o.info.iter), (name, int(info.iter), int(o.info.iter))
         assert rel(x, o.x) <= 1e-8 and rel(y, o.y) <= 1e-8, name
         _kkt_check(p, x, y)
+
+
+def test_sparse_factor_nonconvex_warm_start_updates_and_queue(ctx):
+    """the rest of the loop on a sparse batch: an indefinite Q (LOBPCG front-end, proximal penalty 1 / |lambda|, L D L' with negative pivots),
+    a warm-started re-solve after update_bounds / update_q, and more QPs than resident factor slots (the values of a slot are reused by
+    the next QP of the work queue, the symbolic arrays stay per QP)"""
+    ctx.set_option("sparse_factor", 1)
+    try:
+        # (a) nonconvex
+        p = sparse_qp(72, "blocks", seed=41)
+        Q = sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(p.n, p.n)).tolil()
+        for j in range(0, p.n, 4):
+            Q[j, j] = Q[j, j] - 3.0 * abs(Q[j, j])
+        Q = sp.csc_matrix(Q); Q.sort_indices()
+        p2 = type(p)(p.n, p.m, Q.indptr.astype(np.int64), Q.indices.astype(np.int64), Q.data.copy(), p.Ap, p.Ai, p.Ax, p.q, p.bmin, p.bmax)
+        st = dict(ST, nonconvex=1)
+        bt = QpalmBatch(ctx, [p2], ctx.default_settings(**st))
+        bt.solve()
+        o = oracle_sparse(p2, **st)
+        assert int(bt.stats(0).nonconvex) == o.counter("nonconvex") == 1
+        assert int(bt.info(0).status_val) == o.status_val and int(bt.info(0).iter) == int(o.info.iter)
+        x, y = bt.solution()
+        assert rel(x[0], o.x) <= 1e-8 and rel(y[0], o.y) <= 1e-8
+        bt.close()
+        # (b) update_bounds / update_q + warm start
+        p = sparse_qp(80, "banded", seed=42)
+        bt = QpalmBatch(ctx, [p], ctx.default_settings(**ST))
+        o = ob.OracleQP(*p.args(), settings=ob.default_settings(**ST)); o.set_scalar("sparse_mode", 1)
+        bt.solve(); o.solve()
+        x, y = bt.solution()
+        bmin2, bmax2, q2 = p.bmin - 0.05, p.bmax + 0.1, p.q * 1.1
+        bt.update_bounds(bmin2[None, :], bmax2[None, :]); bt.update_q(q2[None, :]); bt.warm_start(x, y)
+        o.update_bounds(bmin2, bmax2); o.update_q(q2); o.warm_start(o.x, o.y)
+        bt.solve(); o.solve()
+        x, y = bt.solution()
+        assert int(bt.info(0).status_val) == o.status_val == 1 and int(bt.info(0).iter) == int(o.info.iter)
+        assert rel(x[0], o.x) <= 1e-8 and rel(y[0], o.y) <= 1e-8
+        bt.close()
+        # (c) more QPs than slots
+        probs = [sparse_qp(40 + 4 * (k % 3), ("banded", "blocks", "arrow")[k % 3], seed=50 + k) for k in range(7)]
+        ctx.set_option("max_slots", 2)
+        bt = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
+        bt.solve()
+        x, y = bt.solution()
+        for k, p in enumerate(probs):
+            o = oracle_sparse(p, **ST)
+            assert int(bt.info(k).status_val) == o.status_val == 1 and int(bt.info(k).iter) == int(o.info.iter), k
+            assert rel(x[k][:p.n], o.x) <= 1e-9 and rel(y[k][:p.m], o.y) <= 1e-9, k
+        bt.close()
+    finally:
+        ctx.set_option("max_slots", 512)
+        ctx.set_option("sparse_factor", -1)
