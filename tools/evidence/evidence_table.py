@@ -7,7 +7,7 @@ import os
 import re
 import sys
 
-d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r04", "final")
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r05", "final")
 J = lambda f: json.load(open(os.path.join(d, f)))
 b = J("bench_default.json")
 r, st = b["roofline"], b["solve_stats"]
