@@ -72,7 +72,7 @@ def parse_args(argv=None):
                          "executes the multi-GPU path's RCCL initialisation and device-view gather on a single-GPU box (tests/test_bench_launcher.py)")
     ap.add_argument("--kkt", action="store_true", help="factorization_method = FACTORIZE_KKT: the (n+m) x (n+m) KKT panel with row additions / deletions "
                                                         "(what BASELINE.json config 3 literally names) instead of the Schur panel with rank updates")
-    ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance)")
+    ap.add_argument("--small-workgroups", type=int, default=1, help="0: run small QPs on the 512-thread instance too (A/B of the 256-thread instance); 2: on the 128-thread instance (seven workgroups per CU)")
     ap.add_argument("--narrow-rows", type=int, default=1, help="0: Schur assembly with one wavefront per column also for small QPs (A/B)")
     ap.add_argument("--place-panel-wave", type=int, default=-1, help="0: every workgroup runs its serial chains on wavefront 0; 1: panel waves placed on SIMDs 0 / 1; 2: + row ownership by SIMD (A/B; default: the library's)")
     ap.add_argument("--sweep-ranks", type=int, default=0, help="most ranks per sweep of the rank update: 16 or 32 (A/B; 0: library default = 16)")
@@ -369,8 +369,8 @@ def worker(args):
         ctx.set_option("coop_max_batch", args.coop_max_batch)
     if args.kkt_compact >= 0:
         ctx.set_option("kkt_compact", args.kkt_compact)
-    if not args.small_workgroups:
-        ctx.set_option("small_workgroups", 0)
+    if args.small_workgroups != 1:
+        ctx.set_option("small_workgroups", args.small_workgroups)
     if args.place_panel_wave >= 0:
         ctx.set_option("place_panel_wave", args.place_panel_wave)
     if not args.narrow_rows:

@@ -135,7 +135,9 @@ void qpg_ctx_destroy(qpg_ctx *ctx);
  *   "max_slots"             resident factor panels = workgroups in flight (default 512)
  *   "lds_bytes"             dynamic LDS per 512-thread workgroup
  *   "update_rank_threshold" -1 = the reference's refactorise-or-update rule (newton.c:98-101), k >= 0: refactorise beyond k changed rows
- *   "small_workgroups"      1 = factors of at most 256 rows run on the 256-thread instance of the kernels
+ *   "small_workgroups"      1 = factors of at most 256 rows run on the 256-thread instance of the kernels (four workgroups per CU), and
+ *                           batches of more than 2 max_slots QPs with factors of at most 192 rows on the 128-thread instance (seven per CU);
+ *                           2 = the 128-thread instance wherever its 21.5 KB of LDS fit, 3 = never the 128-thread one, 0 = neither
  *   "narrow_rows"           1 = quarter-wavefront Schur assembly for short rows of A
  *   "ld_align"              leading dimension of the factor panels in doubles (16 = every column on a 128-byte line)
  *   "sweep_ranks"           16 (default) or 32 ranks per update sweep (32: the multi-pass sweep, bit-identical factors, slower)

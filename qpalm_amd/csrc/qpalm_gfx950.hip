@@ -45,9 +45,43 @@ static_assert(sizeof(UpdownLds<1, 8>) <= 38912 && sizeof(FactorLds) + sizeof(Fac
               "the 256-thread instance runs with 38 KB of dynamic LDS");
 }
 #undef QP_T
+#undef QP_KSEL
+#undef QP_FKC
+#undef QP_USQ
+#undef QP_UNBS
+#undef QPALM_KERNELS_H
+#undef QPALM_DEVICE_H
+#undef QPALM_DENSE_H
+#undef QPALM_ITER_H
+#undef QPALM_KKT_H
+#undef QPALM_SPARSE_H
+#ifndef QP_TINY_K
+#define QP_TINY_K 8 /* ranks per update sweep of the 128-thread instance */
+#endif
+#ifndef QP_LDS_TINY
+#define QP_LDS_TINY 22016
+#endif
+#ifndef QP_TINY_PER_CU
+#define QP_TINY_PER_CU 7
+#endif
+#define QP_T 128
+#define QP_KSEL(RPT) QP_TINY_K
+#define QP_FKC 8
+#define QP_USQ 0
+#define QP_UNBS 16
+#define QP_FST 2
+namespace qp128 {
+#include "qpalm_kernels.h"
+static_assert(sizeof(UpdownLds<2, QP_TINY_K>) <= QP_LDS_TINY && sizeof(FactorLds) + sizeof(FactorStage) + 64 <= QP_LDS_TINY && sizeof(SolveLds) + 8 * 256 <= QP_LDS_TINY,
+              "the 128-thread instance runs with 21.5 KB of dynamic LDS");
+static_assert((sizeof(IterShared) + QP_LDS_TINY) * QP_TINY_PER_CU <= 160 * 1024, "workgroups of the 128-thread instance per CU");
+}
+#undef QP_FST
+#undef QP_T
 #define QP_T 512 /* the general instance's workgroup size (limits quoted by the host code) */
 #define QP_T_SMALL 256
 #define QP_LDS_SMALL 38912
+#define QP_T_TINY 128
 #define QP_TWO_INSTANCES 1
 
 /* per host thread: qpg_batch_create allocates the device arena on a thread of its own, whose failure reaches the caller through

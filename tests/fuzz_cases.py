@@ -237,6 +237,18 @@ def noise_decided_branch(ctx, p, st, warm, cap=3000):
                     if newton_side_unchanged:
                         return True, ("iteration %d: engine kind %d, oracle kind %d after a full Newton step (tau = 1) on an unchanged active set: inner residuals %.3e / %.3e "
                                       "are the rounding error of the two solves (%.3e before the step)" % (k, ek, ok_, e2, o2, prev_big))
+                if int(info.status_val) == -3 and ok_ == 0 and k >= 1 and int(t["kind"][k - 1]) == 0 and prev_kind_e == 0:
+                    # the engine stops on the primal-infeasibility certificate where the oracle takes a Newton step: the oracle's vectors of
+                    # this iteration from a second run that stops right after it (max_iter = k + 1; the Newton step leaves yh, Atyh, dphi alone)
+                    o2_ = ob.OracleQP(*p.args(), settings=ob.default_settings(**dict(st, max_iter=k + 1)))
+                    if warm is not None:
+                        o2_.warm_start(warm[0], warm[1])
+                    o2_.solve()
+                    try:
+                        return _certificate_on_rounding(st, k, float(t["tau"][k - 1]), int(t["nb_enter"][k]) + int(t["nb_leave"][k]),
+                                                        _certificate_terms(lambda name: bt.vec(name, 0), p, st), _certificate_terms(o2_.vec, p, st), "engine")
+                    finally:
+                        o2_.cleanup()
                 return False, "iteration %d: engine kind %d (dua2 %.3e), oracle kind %d (dua2 %.3e), before the step %.3e" % (k, ek, e2, ok_, o2, prev_big)
             if int(info.status_val) != -10:
                 return False, "same kinds up to termination at iteration %d" % k
@@ -246,7 +258,50 @@ def noise_decided_branch(ctx, p, st, warm, cap=3000):
             prev_kind_e = ek
             if ek == 0:
                 prev_big = max(e2, o2)   # kind 0: a Newton step is taken from this residual
+        k = len(t["kind"])
+        if k < cap and k >= 1 and int(o.status_val) == -3 and int(t["kind"][k - 1]) == 0 and prev_kind_e == 0:
+            # the oracle stopped on the primal-infeasibility certificate after these iterations: does the engine take one more Newton step?
+            bt.iterate(1)
+            s, info = bt.stats(0), bt.info(0)
+            if int(info.status_val) == -10 and int(s.last_kind) == 0:
+                return _certificate_on_rounding(st, k, float(t["tau"][k - 1]), int(s.nb_enter) + int(s.nb_leave),
+                                                _certificate_terms(lambda name: bt.vec(name, 0), p, st), _certificate_terms(o.vec, p, st), "oracle")
         return False, "no differing branch found"
     finally:
         bt.close()
         o.cleanup()
+
+
+def _certificate_terms(vec, p, st):
+    """what is_primal_infeasible (termination.c:136-182) compares, from one implementation's workspace after the residual pass of an
+    iteration: T = |Dinv o (A'yh - A'y)|_inf, thr = eps_prim_inf |E o (yh - y)|_inf, and |Dinv o dphi|_inf"""
+    n, m = p.n, p.m
+    scaled = int(st.get("scaling", 10)) > 0
+    Dinv = vec("Dinv")[:n] if scaled else np.ones(n)
+    E = vec("E")[:m] if scaled else np.ones(m)
+    T = float(np.max(np.abs(Dinv * (vec("Atyh")[:n] - vec("Aty")[:n]))))
+    thr = float(st.get("eps_prim_inf", 1e-5)) * float(np.max(np.abs(E * (vec("yh")[:m] - vec("y")[:m]))))
+    return T, thr, float(np.max(np.abs(Dinv * vec("dphi")[:n])))
+
+
+def _certificate_on_rounding(st, k, tau_prev, nchange, a, b, who_stops):
+    """Round 5 (fresh-seed campaign, seed 501 case 280): one implementation stops on the primal-infeasibility certificate at iteration k,
+    the other takes one more Newton step and stops an iteration later.  The certificate compares T = |A'(yh - y)| with eps |yh - y|,
+    and A'yh = dphi - (Qx + q + (x - x0) / gamma): when the step before was a FULL Newton step (tau = 1) and the active set did not
+    change, dphi is ZERO in exact arithmetic -- what each implementation holds in dphi is the rounding error of its own solve, and that
+    error sits in T one to one.  So the two T's may differ by the sum of the two |dphi|, and a threshold between them is decided by that
+    rounding error: accepted iff the thresholds agree, the threshold lies between the two T's, and |T_a - T_b| <= |dphi_a| + |dphi_b|.
+    No fitted constant."""
+    (Ta, thra, na), (Tb, thrb, nb) = a, b
+    what = "iteration %d: the %s stops on the primal-infeasibility certificate, the other side takes a Newton step: T %.6e / %.6e against %.6e / %.6e, |dphi| %.3e / %.3e, tau before %.9f, %d active-set changes" % (
+        k, who_stops, Ta, Tb, thra, thrb, na, nb, tau_prev, nchange)
+    if abs(tau_prev - 1.0) > 1e-6 or nchange != 0:
+        return False, what + " -- not after a full Newton step on an unchanged active set"
+    if abs(thra - thrb) > 1e-6 * max(thra, thrb):
+        return False, what + " -- the thresholds differ"
+    lo, hi = min(Ta, Tb), max(Ta, Tb)
+    if not (lo <= max(thra, thrb) and hi >= min(thra, thrb)):
+        return False, what + " -- the threshold is not between the two values"
+    if hi - lo > na + nb:
+        return False, what + " -- the two values differ by more than the rounding error in dphi"
+    return True, what + ": decided by the rounding error of the two solves"

@@ -15,6 +15,7 @@ and the inner termination test compares rounding noise with its threshold: most 
 Campaign N (round 5) -- the nonconvex front-end: nonconvex = 1 with the diagonal of Q lowered by its mean (a third to a half of the cases
 indefinite: LOBPCG, per-QP gamma, LDL' of indefinite matrices without pivoting).
 Campaign D (round 5) -- dual-objective termination forced (second resident factor LD_Q, DUAL_TERMINATED exit).
+Campaign T (round 5) -- the general stream on the 128-thread instance of the kernels.
 Named cases -- the five mismatches of round 3's end-of-round campaign (profiles/r03/fuzz) and the five of round 4's nonconvex campaign
 (profiles/r04/fuzz), pinned.  Of the latter, three are reproduced count for count by the oracle's own source with its rank-update
 recurrence written in the device code's algebraically equal form (oracle variant "pivot"), one changes its count when the data move
@@ -46,6 +47,23 @@ def test_fuzz_general_campaign(ctx):
         bad += b; soft += s; total += count
     assert not bad, bad
     assert len(soft) <= max(1, total // 100), soft   # rounding-decided cases are rare (round 3: 5 of 1960 fresh cases)
+
+
+def test_fuzz_general_campaign_on_the_128_thread_instance(ctx):
+    """Campaign T (round 5): the general campaign's stream on the third instance of the kernels (128-thread workgroups, seven per CU,
+    16-column sweep blocks, 8-column factor chunks), which batches of more than 1024 small QPs select by themselves -- here forced."""
+    if ctx.kind == "emu":
+        pytest.skip("the emulation build holds one instance of the kernels")
+    bad, soft, total = [], [], 0
+    ctx.set_option("small_workgroups", 2)
+    try:
+        for seed, count, n_lo, n_hi in [(61, 400, 2, 70), (62, 120, 70, 250)]:
+            b, s = _campaign(ctx, seed, count, n_lo, n_hi)
+            bad += b; soft += s; total += count
+    finally:
+        ctx.set_option("small_workgroups", 1)
+    assert not bad, bad
+    assert len(soft) <= max(1, total // 100), soft
 
 
 def test_fuzz_kkt_with_large_sigma(ctx):
@@ -148,6 +166,22 @@ def test_round4_nonconvex_mismatches_are_explained(ctx, seed, case, n_lo, n_hi, 
         assert ok, (seed, case, meta, why, r)
         if seed == 271:   # the oracle with the device code's form of the recurrence reproduces the engine's count
             assert (not rounding) or ("'pivot': (%d, %d)" % (r["status"][0], r["iter"][0]) in why) or ctx.kind == "emu", why
+
+
+def test_round5_certificate_one_iteration_apart_is_explained(ctx):
+    """Fresh-seed campaign at the end of round 5 (profiles/r05/fuzz/general_small_501.log): seed 501 case 280, an infeasible QP on the
+    KKT path with sigma up to 7e7 -- the oracle stops on the primal-infeasibility certificate at iteration 20, the engine one Newton
+    step later; no compiler-flag, formula or one-ulp variant of the oracle moves its count.  The certificate compares |A'(yh - y)| =
+    7.4 (oracle) / 14.7 (engine) with 14.63, after a full Newton step on an unchanged active set that took |dphi| from 3.2e7 to
+    7.1 / 15.3: fuzz_cases._certificate_on_rounding."""
+    for it, p, st, warm, meta in cases(501, 281, 2, 70):
+        if it != 280:
+            continue
+        r = run_case(ctx, p, st, warm)
+        ok, why, rounding = judge_case(r, p, st, warm, 1e-8, ctx)
+        assert ok, (meta, why, r)
+        if r["iter"][0] != r["iter"][1]:
+            assert rounding and "certificate" in why, why
 
 
 @pytest.mark.parametrize("seed,case,n_lo,n_hi", R03_MISMATCHES)

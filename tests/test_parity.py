@@ -570,17 +570,50 @@ def test_workgroup_shapes_and_placement_do_not_change_results(ctx):
     probs = [random_qp(n, m, seed=5100 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(sizes(ctx, 2, 6))]
     st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     try:
-        for small, place in ((1, 1), (0, 1), (1, 0), (0, 0), (0, 2)):   # place 2: rows owned by SIMD (512-thread instance)
-            ctx.set_option("small_workgroups", small)
+        for small, place in ((1, 1), (0, 1), (1, 0), (0, 0), (0, 2), (2, 0), (2, 1)):   # place 2: rows owned by SIMD (512-thread instance)
+            ctx.set_option("small_workgroups", small)                   # small 2: the 128-thread instance (seven workgroups per CU)
             ctx.set_option("place_panel_wave", place)
             bt = _compare_solve(ctx, probs, st)
             wgs, threads, lds = bt.launch_shape()
-            assert wgs >= 1 and lds >= 32 * 1024
+            assert wgs >= 1 and lds >= (16 if small == 2 else 32) * 1024
             if ctx.kind == "hip":
-                assert threads == (256 if small else 512)
+                assert threads == {0: 512, 1: 256, 2: 128}[small]
     finally:
         ctx.set_option("small_workgroups", 1)
         ctx.set_option("place_panel_wave", 0)
+
+
+def test_large_batches_of_small_qps_run_on_the_128_thread_instance(ctx):
+    """more QPs than the 256-thread instance keeps resident (1024), factors of at most 192 rows: the library picks the 128-thread
+    instance (seven workgroups per CU: 1792 QPs in flight) by itself -- every QP of the batch against the oracle, through the work queue"""
+    if ctx.kind != "hip":
+        pytest.skip("the emulation build holds one instance of the kernels")
+    distinct = [random_qp(48, 96, seed=5300 + k, density_A=0.08, density_M=0.04) for k in range(24)]
+    probs = [distinct[k % len(distinct)] for k in range(2000)]
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    bt = QpalmBatch(ctx, probs, ctx.default_settings(**st))
+    wgs, threads, lds = bt.launch_shape()
+    assert threads == 128 and wgs == 1792, (wgs, threads, lds)
+    bt.solve()
+    xs, ys = bt.solution()
+    ref = []
+    for p in distinct:
+        o = oracle_for(p, st)
+        o.solve()
+        ref.append((o.status_val, int(o.info.iter), o.x.copy(), o.y.copy()))
+    for k in range(len(probs)):
+        stv, it, x, y = ref[k % len(distinct)]
+        info = bt.info(k)
+        assert int(info.status_val) == stv and int(info.iter) == it, (k, int(info.iter), it)
+        assert rel(xs[k], x) <= RTOL and rel(ys[k], y) <= RTOL
+    bt.close()
+    ctx.set_option("small_workgroups", 3)     # the same batch on the 256-thread instance
+    try:
+        bt = QpalmBatch(ctx, probs[:1100], ctx.default_settings(**st))
+        assert bt.launch_shape()[1] == 256
+        bt.close()
+    finally:
+        ctx.set_option("small_workgroups", 1)
 
 
 def _with_long_row_and_column(p, seed):
