@@ -143,6 +143,7 @@ void qpg_ctx_destroy(qpg_ctx *ctx);
  *   "sweep_ranks"           16 (default) or 32 ranks per update sweep (32: the multi-pass sweep, bit-identical factors, slower)
  *   "kkt_compact"           1 = FACTORIZE_KKT factorises the variables + ACTIVE constraints only and spreads the factor out on demand
  *   "place_panel_wave"      0 / 1 / 2: SIMD placement of the sweeps' panel wavefronts (0 = the hardware's own)
+ *   "sparse_factor", "sparse_ordering"   the sparse L D L' and its ordering (qpg_batch_sparse_info / qpg_batch_sparse_perm below)
  *   "coop", "coop_workgroups", "coop_updates", "coop_rank_threshold"   one large QP on many workgroups
  * Environment: QPALM_HOST_THREADS = host threads of qpg_batch_set_problems (default: hardware threads, at most 24). */
 int  qpg_ctx_set_option(qpg_ctx *ctx, const char *name, qpg_int value);
@@ -187,6 +188,12 @@ int  qpg_batch_launch_shape(qpg_batch *bt, qpg_int *workgroups, qpg_int *threads
  * 0 never; Schur path, no dual termination).  nnzL: entries of the member's strict lower triangle; device_bytes: the block that holds
  * the symbolic arrays of all members and the values of all resident factors.  QPG_ERR_UNSUPPORTED on a batch with dense factors. */
 int  qpg_batch_sparse_info(qpg_batch *bt, qpg_int idx, qpg_int *nnzL, qpg_int *device_bytes);
+/* The ordering of member idx's sparse factor, P H P' = L D L': perm[new] = old (n entries), and the height of its elimination tree.
+ * The reference configures CHOLMOD_NATURAL (solver_interface.c:530-540: identity); context option "sparse_ordering" = 1 orders by
+ * nested dissection instead, -1 (default) does so where the natural tree is deep (a band: one column per level) and dissection makes it
+ * at least four times shallower -- the factorisation and the solves run at the latency of the tree's height.  Changes rounding, not
+ * what is computed. */
+int  qpg_batch_sparse_perm(qpg_batch *bt, qpg_int idx, qpg_int *perm, qpg_int *levels);
 int  qpg_batch_update_settings(qpg_batch *bt, const QPGSettings *s);
 int  qpg_batch_update_bounds(qpg_batch *bt, const qpg_float *bmin, const qpg_float *bmax); /* [B][m] or NULL */
 int  qpg_batch_update_q(qpg_batch *bt, const qpg_float *q);                              /* [B][n] */

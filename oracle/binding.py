@@ -113,6 +113,10 @@ def _declare(L):
     L.oq_get_matrix.argtypes = [C.c_void_p, C.c_char_p, pi, pi, C.POINTER(pi), C.POINTER(pi), C.POINTER(pf)]
     L.oq_get_factor.restype = pf
     L.oq_get_factor.argtypes = [C.c_void_p, C.POINTER(pf), pi]
+    L.oq_set_perm.restype = c_int
+    L.oq_set_perm.argtypes = [C.c_void_p, pi, c_int]
+    L.oq_sparse_levels.restype = c_int
+    L.oq_sparse_levels.argtypes = [C.c_void_p]
     L.oq_get_kkt_factor.restype = pf
     L.oq_get_kkt_factor.argtypes = [C.c_void_p, C.POINTER(pf), pi]
     for f in ("oq_kkt_form_and_factor", "oq_kkt_update_entering_constraints", "oq_kkt_update_leaving_constraints", "oq_kkt_solve"):
@@ -249,6 +253,15 @@ class OracleQP:
 
     def set_scalar(self, name, v):
         self.L.oq_set_scalar(self.w, name.encode(), float(v))
+
+    def set_perm(self, perm):
+        """sparse-storage mode: factorise P H P' under this symmetric permutation (perm[new] = old), before the first solve"""
+        a = np.ascontiguousarray(perm, dtype=np.int64)
+        if self.L.oq_set_perm(self.w, a.ctypes.data_as(C.POINTER(c_int)), len(a)) != 0:
+            raise ValueError("not a permutation of 0 .. n-1 (or the factor exists already)")
+
+    def sparse_levels(self):
+        return int(self.L.oq_sparse_levels(self.w))
 
     def counter(self, name):
         return int(self.L.oq_get_counter(self.w, name.encode()))

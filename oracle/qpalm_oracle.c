@@ -93,6 +93,8 @@ struct oq_workspace {
   oq_int sp_nlev;                                   /* height of the elimination tree (levels) */
   oq_int *sp_Lp, *sp_Li, *sp_Rp, *sp_Rk, *sp_Rpos; /* pattern of L by columns (strict lower, rows ascending) and by rows (columns ascending) */
   oq_float *sp_Lx, *sp_D, *sp_y;                    /* values on that pattern, pivots, dense work vector (zero outside of use) */
+  oq_int *sp_perm, *sp_iperm;                       /* optional symmetric permutation of the factor: P H P' = L D L', perm[new] = old (oq_set_perm; NULL: natural ordering) */
+  oq_float *sp_b;                                   /* permuted right-hand side of a solve */
   /* settings / solution / info */
   oq_settings settings;
   oq_float *sol_x, *sol_y;
@@ -676,7 +678,7 @@ void oq_cleanup(oq_workspace *w) {
   factor_free(&w->LD); factor_free(&w->LD_Q); factor_free(&w->LDK);
   free(w->kkt_state); free(w->rhs_kkt); free(w->sol_kkt); free(w->kkt_tmp);
   if (w->At.p) sp_free(&w->At);
-  free(w->sp_Lp); free(w->sp_Li); free(w->sp_Rp); free(w->sp_Rk); free(w->sp_Rpos); free(w->sp_Lx); free(w->sp_D); free(w->sp_y);
+  free(w->sp_Lp); free(w->sp_Li); free(w->sp_Rp); free(w->sp_Rk); free(w->sp_Rpos); free(w->sp_Lx); free(w->sp_D); free(w->sp_y); free(w->sp_perm); free(w->sp_iperm); free(w->sp_b);
   free(w);
 }
 
@@ -866,7 +868,11 @@ static void boost_gamma(oq_workspace *w) { /* iteration.c:158-211 */
  * sparse-storage mode (see oq_workspace.sparse_mode)
  * ======================================================================================= */
 static int cmp_int(const void *a, const void *b) { oq_int x = *(const oq_int *)a, y = *(const oq_int *)b; return (x > y) - (x < y); }
-/* pattern of L for H = Q + A'A with ALL rows of A, natural ordering: struct(L_j) = struct(H_j) u U_{children} struct(L_c) \ {c} */
+/* pattern of L for H = Q + A'A with ALL rows of A: struct(L_j) = struct(H_j) u U_{children} struct(L_c) \ {c}.  Natural ordering (the
+ * reference's: solver_interface.c:530-540) unless the test handed over the engine's fill- / depth-reducing permutation (oq_set_perm):
+ * then everything below -- pattern, values, work vectors -- lives in the permuted numbering, IP(i) = iperm[i]. */
+#define IP(i) (w->sp_iperm ? w->sp_iperm[i] : (i))
+#define PO(j) (w->sp_perm ? w->sp_perm[j] : (j))
 static void sparse_analyze(oq_workspace *w) {
   oq_int n = w->n;
   const oq_sparse *Q = &w->Q, *A = &w->A;
@@ -876,13 +882,32 @@ static void sparse_analyze(oq_workspace *w) {
   size_t cap = (size_t)(Q->p[n] + A->p[n] + n + 16), nz = 0;
   oq_int *Li = (oq_int *)malloc(cap * sizeof(oq_int)), *col = izalloc((size_t)n);
   for (oq_int j = 0; j < n; j++) { mark[j] = -1; head[j] = -1; next[j] = -1; }
+  oq_int *qp = NULL, *qi = NULL;
+  if (w->sp_perm) { /* entry (r, c), r > c, of Q sits at (max, min) of (iperm[r], iperm[c]) */
+    qp = izalloc((size_t)n + 1); qi = izalloc(nz1((size_t)Q->p[n]));
+    for (int pass = 0; pass < 2; pass++) {
+      for (oq_int c = 0; c < n; c++)
+        for (oq_int k = Q->p[c]; k < Q->p[c + 1]; k++) {
+          oq_int r = Q->i[k];
+          if (r <= c) continue;
+          oq_int a = IP(r), b2 = IP(c), lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+          if (pass == 0) qp[lo + 1]++; else qi[next[lo]++] = hi;
+        }
+      if (pass == 0) { for (oq_int j = 0; j < n; j++) { qp[j + 1] += qp[j]; next[j] = qp[j]; } }
+    }
+    for (oq_int j = 0; j < n; j++) next[j] = -1;
+  }
   for (oq_int j = 0; j < n; j++) {
     oq_int cnt = 0;
     mark[j] = j;
-    for (oq_int k = Q->p[j]; k < Q->p[j + 1]; k++) { oq_int i = Q->i[k]; if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
-    for (oq_int p = A->p[j]; p < A->p[j + 1]; p++) {
+    if (!w->sp_perm) {
+      for (oq_int k = Q->p[j]; k < Q->p[j + 1]; k++) { oq_int i = Q->i[k]; if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
+    } else { /* the stored (lower) triangle of Q in the permuted numbering, bucketed by column (qp / qi below) */
+      for (oq_int k = qp[j]; k < qp[j + 1]; k++) { oq_int i = qi[k]; if (mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
+    }
+    for (oq_int p = A->p[PO(j)]; p < A->p[PO(j) + 1]; p++) {
       oq_int t = A->i[p];
-      for (oq_int q = T.p[t]; q < T.p[t + 1]; q++) { oq_int i = T.i[q]; if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
+      for (oq_int q = T.p[t]; q < T.p[t + 1]; q++) { oq_int i = IP(T.i[q]); if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
     }
     for (oq_int c = head[j]; c >= 0; c = next[c])
       for (oq_int e = Lp[c]; e < Lp[c + 1]; e++) { oq_int i = Li[e]; if (i > j && mark[i] != j) { mark[i] = j; col[cnt++] = i; } }
@@ -907,9 +932,9 @@ static void sparse_analyze(oq_workspace *w) {
     w->sp_nlev = nlev;
     free(lev);
   }
-  free(mark); free(head); free(next); free(col); free(cur); sp_free(&T);
+  free(mark); free(head); free(next); free(col); free(cur); free(qp); free(qi); sp_free(&T);
   w->sp_Lp = Lp; w->sp_Li = Li; w->sp_Rp = Rp; w->sp_Rk = Rk; w->sp_Rpos = Rpos;
-  w->sp_Lx = zalloc(nz); w->sp_D = zalloc((size_t)n); w->sp_y = zalloc((size_t)n);
+  w->sp_Lx = zalloc(nz); w->sp_D = zalloc((size_t)n); w->sp_y = zalloc((size_t)n); w->sp_b = zalloc((size_t)n);
 }
 static oq_int sparse_pos(const oq_workspace *w, oq_int i, oq_int j) { /* position of L(i, j), i > j */
   const oq_int *base = w->sp_Li + w->sp_Lp[j];
@@ -929,9 +954,9 @@ static void sparse_factor(oq_workspace *w, int with_AtSA, int add_beta, oq_float
     for (oq_int t = 0; t < w->m; t++) {
       if (!w->active[t]) continue;
       for (oq_int b = F->p[t]; b < F->p[t + 1]; b++) {
-        oq_float vb = F->x[b]; oq_int cb = F->i[b];
+        oq_float vb = F->x[b]; oq_int cb = IP(F->i[b]);
         for (oq_int a = F->p[t]; a < F->p[t + 1]; a++) {
-          oq_int ra = F->i[a];
+          oq_int ra = IP(F->i[a]);
           if (ra == cb) D[cb] += F->x[a] * vb; else if (ra > cb) Lx[sparse_pos(w, ra, cb)] += F->x[a] * vb;
         }
       }
@@ -941,7 +966,8 @@ static void sparse_factor(oq_workspace *w, int with_AtSA, int add_beta, oq_float
   for (oq_int j = 0; j < n; j++)
     for (oq_int k = Q->p[j]; k < Q->p[j + 1]; k++) {
       oq_int i = Q->i[k];
-      if (i == j) D[j] = Q->x[k] + D[j]; else if (i > j) { oq_int e = sparse_pos(w, i, j); Lx[e] = Q->x[k] + Lx[e]; }
+      if (i == j) D[IP(j)] = Q->x[k] + D[IP(j)];
+      else if (i > j) { oq_int a = IP(i), b2 = IP(j); oq_int e = sparse_pos(w, a > b2 ? a : b2, a > b2 ? b2 : a); Lx[e] = Q->x[k] + Lx[e]; }
     }
   if (add_beta) for (oq_int j = 0; j < n; j++) D[j] += beta;
   for (oq_int k = 0; k < n; k++) { /* row k: its structural nonzeros are the columns Rk[Rp[k] .. Rp[k+1]), ascending */
@@ -967,8 +993,8 @@ static void sparse_rank1(oq_workspace *w, oq_int t, int update) {
   const oq_sparse *F = &w->At_sqrt_sigma;
   if (F->p[t + 1] <= F->p[t]) return;
   oq_float *v = w->sp_y, alpha = 1.0;
-  for (oq_int k = F->p[t]; k < F->p[t + 1]; k++) v[F->i[k]] = F->x[k];
-  oq_int j = F->i[F->p[t]];
+  oq_int j = w->n;
+  for (oq_int k = F->p[t]; k < F->p[t + 1]; k++) { oq_int i = IP(F->i[k]); v[i] = F->x[k]; if (i < j) j = i; } /* the path starts at the row's first column */
   while (j >= 0) {
     oq_float wj = v[j], dj = w->sp_D[j], a, gam;
     if (update) { a = alpha + (wj * wj) / dj; dj *= a; gam = -wj / dj; }
@@ -988,11 +1014,14 @@ static void sparse_rank1(oq_workspace *w, oq_int t, int update) {
 }
 /* the engine's rule (qpalm_sparse.h: sp_update_pays): walking nchange paths of at most nlev columns against refactorising n columns */
 static int sparse_update_pays(const oq_workspace *w, oq_int nchange) { return w->sparse_mode == 1 && (long long)nchange * (long long)w->sp_nlev * 2 < (long long)w->n; }
-static void sparse_solve(oq_workspace *w, oq_float *b) { /* oq_dense_ldl_solve on the compressed columns */
+static void sparse_solve(oq_workspace *w, oq_float *b_) { /* oq_dense_ldl_solve on the compressed columns (of P H P': x = P' (L D L')^-1 P b) */
   oq_int n = w->n;
+  oq_float *b = b_;
+  if (w->sp_perm) { b = w->sp_b; for (oq_int j = 0; j < n; j++) b[j] = b_[w->sp_perm[j]]; }
   for (oq_int j = 0; j < n; j++) { oq_float yj = b[j]; for (oq_int e = w->sp_Lp[j]; e < w->sp_Lp[j + 1]; e++) b[w->sp_Li[e]] -= w->sp_Lx[e] * yj; }
   for (oq_int j = 0; j < n; j++) b[j] /= w->sp_D[j];
   for (oq_int j = n - 1; j >= 0; j--) { oq_float xj = b[j]; for (oq_int e = w->sp_Lp[j]; e < w->sp_Lp[j + 1]; e++) xj -= w->sp_Lx[e] * b[w->sp_Li[e]]; b[j] = xj; }
+  if (w->sp_perm) for (oq_int j = 0; j < n; j++) b_[w->sp_perm[j]] = b[j];
 }
 /* gershgorin_max_AtsigmaA without the n x n buffer: one column of C = F F' at a time in the dense work vector, summed over the touched
  * rows in ascending order (the dense routine walks i = 0 .. n-1 over its pattern map) */
@@ -1841,6 +1870,18 @@ const oq_float *oq_get_kkt_factor(const oq_workspace *w, const oq_float **D, oq_
   if (ld) *ld = w->n + w->m;
   return w->LDK.L;
 }
+/* TEST INFRASTRUCTURE: the symmetric permutation the sparse-storage mode factorises under (the engine's, read back through
+ * qpg_batch_sparse_perm by tests/test_sparse_factor.py), before the first solve; perm[new] = old */
+int oq_set_perm(oq_workspace *w, const oq_int *perm, oq_int n) {
+  if (!w || n != w->n || w->sp_Lp) return 1;
+  oq_int *pm = izalloc(nz1((size_t)n)), *ip = izalloc(nz1((size_t)n));
+  for (oq_int j = 0; j < n; j++) ip[j] = -1;
+  for (oq_int j = 0; j < n; j++) { if (perm[j] < 0 || perm[j] >= n || ip[perm[j]] >= 0) { free(pm); free(ip); return 1; } pm[j] = perm[j]; ip[perm[j]] = j; }
+  free(w->sp_perm); free(w->sp_iperm);
+  w->sp_perm = pm; w->sp_iperm = ip;
+  return 0;
+}
+oq_int oq_sparse_levels(const oq_workspace *w) { return w->sp_nlev; }
 const oq_float *oq_get_factor(const oq_workspace *w_, const oq_float **D, oq_int *ld) {
   oq_workspace *w = (oq_workspace *)w_;
   if (w->sparse_mode && w->sp_Lp) { /* tests of the sparse-storage mode on small problems: the compressed columns spread out into the dense layout */

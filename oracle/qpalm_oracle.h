@@ -144,6 +144,8 @@ const oq_settings *oq_get_settings(const oq_workspace *w);
 void      oq_get_matrix(oq_workspace *w, const char *name, oq_int *nrow, oq_int *ncol,
                         oq_int **p, oq_int **i, oq_float **x);       /* "A","Q","At_sqrt_sigma" */
 const oq_float *oq_get_factor(const oq_workspace *w, const oq_float **D, oq_int *ld);
+int       oq_set_perm(oq_workspace *w, const oq_int *perm, oq_int n); /* sparse-storage mode: factorise P H P' (perm[new] = old); 0 = accepted */
+oq_int    oq_sparse_levels(const oq_workspace *w);                    /* height of the elimination tree after the first factorisation */
 /* KKT path, operation by operation (solver_interface.h:82-126; workspaces set up with factorization_method = FACTORIZE_KKT) */
 void oq_kkt_form_and_factor(oq_workspace *w);
 void oq_kkt_update_entering_constraints(oq_workspace *w);

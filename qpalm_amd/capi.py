@@ -89,6 +89,7 @@ def load(path=None):
     L.qpg_batch_num_unfinished.argtypes = [C.c_void_p, pi]
     L.qpg_batch_launch_shape.argtypes = [C.c_void_p, pi, pi, pi]
     L.qpg_batch_sparse_info.argtypes = [C.c_void_p, c_int, pi, pi]
+    L.qpg_batch_sparse_perm.argtypes = [C.c_void_p, c_int, pi, pi]
     L.qpg_batch_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.qpg_batch_update_settings.argtypes = [C.c_void_p, C.POINTER(Settings)]
     L.qpg_batch_update_bounds.argtypes = [C.c_void_p, pf, pf]
@@ -132,7 +133,7 @@ def load(path=None):
 SYMBOLS = [
     "qpg_last_error", "qpg_backend_name", "qpg_set_default_settings", "qpg_validate_settings", "qpg_ctx_create",
     "qpg_ctx_destroy", "qpg_ctx_set_option", "qpg_batch_create", "qpg_batch_set_problem", "qpg_batch_setup",
-    "qpg_batch_warm_start", "qpg_batch_warm_start_last", "qpg_batch_solve", "qpg_batch_iterate", "qpg_batch_last_solve_ms", "qpg_batch_num_unfinished", "qpg_batch_launch_shape", "qpg_batch_sparse_info",
+    "qpg_batch_warm_start", "qpg_batch_warm_start_last", "qpg_batch_solve", "qpg_batch_iterate", "qpg_batch_last_solve_ms", "qpg_batch_num_unfinished", "qpg_batch_launch_shape", "qpg_batch_sparse_info", "qpg_batch_sparse_perm",
     "qpg_batch_update_settings", "qpg_batch_update_bounds", "qpg_batch_update_q", "qpg_batch_get_info",
     "qpg_batch_get_stats", "qpg_batch_get_solution", "qpg_batch_get_vector", "qpg_batch_set_vector",
     "qpg_batch_get_ivector", "qpg_batch_set_ivector", "qpg_batch_set_scalar", "qpg_batch_get_factor",

@@ -9,7 +9,9 @@
  *    of every active set's pattern, so the structure never changes while constraints enter and leave), elimination tree, pattern of
  *    L by columns (strict lower part, rows ascending), the same entries by rows (column + position in the column arrays, columns
  *    ascending) and the level sets of the elimination tree.  Natural ordering: what the reference configures
- *    (solver_interface.c:530-540, c->nmethods = 1, method[0].ordering = CHOLMOD_NATURAL).
+ *    (solver_interface.c:530-540, c->nmethods = 1, method[0].ordering = CHOLMOD_NATURAL) -- or, context option "sparse_ordering", a
+ *    nested dissection (qpalm_capi.inc: sparse_order) under which the factor is that of P H P': the kernels below then work in the
+ *    permuted numbering (perm, AtiP, QfiP, first) and the solve permutes its right-hand side in and out.
  *  - Numeric factorisation: left-looking by columns, the columns of one level of the elimination tree in parallel (one wavefront
  *    per column, lanes over the entries), a level ends with a workgroup barrier.  A column is assembled AND updated in a dense work
  *    vector of its wavefront (HBM, n doubles, zero outside of use): A' Sigma A first (active rows t of A(:, j) ascending, as
@@ -29,16 +31,18 @@
 
 struct SpArrays { /* this QP's symbolic arrays + this slot's values and work vectors */
   const int *Lp, *Li, *Rp, *Rk, *Rpos, *levptr, *levcol;
+  const int *perm, *AtiP, *QfiP, *first; /* the factor's numbering (P H P'): perm[new] = old; Ati and Qfi renumbered; every row of A's first column */
   int nlev;
-  double *Lx, *Dg, *wv;
+  double *Lx, *Dg, *wv, *tmp;
 };
 QPD SpArrays sp_arrays(const qpg_view &V, int b, int slot, double *Dg) {
   SpArrays s;
   s.Lp = V.sp_Lp + (size_t)b * (V.n + 1); s.Li = V.sp_Li + (size_t)b * V.sp_nnzL;
   s.Rp = V.sp_Rp + (size_t)b * (V.n + 1); s.Rk = V.sp_Rk + (size_t)b * V.sp_nnzL; s.Rpos = V.sp_Rpos + (size_t)b * V.sp_nnzL;
   s.levptr = V.sp_levptr + (size_t)b * (V.n + 1); s.levcol = V.sp_levcol + (size_t)b * V.n;
+  s.perm = V.sp_perm + (size_t)b * V.n; s.AtiP = V.sp_AtiP + (size_t)b * V.nnzA; s.QfiP = V.sp_QfiP + (size_t)b * V.nnzQf; s.first = V.sp_first + (size_t)b * V.m;
   s.nlev = V.sp_nlev[b];
-  s.Lx = V.sp_Lx + (size_t)slot * V.sp_nnzL; s.Dg = Dg; s.wv = V.sp_wv + (size_t)slot * QP_NW * V.n;
+  s.Lx = V.sp_Lx + (size_t)slot * V.sp_nnzL; s.Dg = Dg; s.wv = V.sp_wv + (size_t)slot * QP_NW * V.n; s.tmp = V.sp_tmp + (size_t)slot * V.n;
   return s;
 }
 
@@ -52,11 +56,11 @@ QPD bool sp_level_needs_barrier(const SpArrays &S, int lev) {
 QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, bool with_AtSA, bool proximal, double gamma) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
-  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
+  const int *Atp = V.Atp + (size_t)b * (V.m + 1);
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
   const int *Ainv = V.Ainv + (size_t)b * V.nnzA;
-  const int *Qp = V.Qp + (size_t)b * (V.n + 1), *Qi = V.Qi + (size_t)b * V.nnzQ;
-  const double *Qx = V.Qx + (size_t)b * V.nnzQ;
+  const int *Qfp = V.Qfp + (size_t)b * (V.n + 1);
+  const double *Qfx = V.Qfx + (size_t)b * V.nnzQf;
   const int *active = V.active + (size_t)b * V.m;
   double *w = S.wv + (size_t)wid * n; /* this wavefront's work vector: zero on entry, zero again when the column is done */
   __syncthreads();
@@ -64,24 +68,25 @@ QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, boo
     const int c0 = S.levptr[lev], c1 = S.levptr[lev + 1];
     for (int c = c0 + wid; c < c1; c += QP_NW) {
       const int j = S.levcol[c];
+      const int jo = S.perm[j]; /* column j of P H P' is column perm[j] of H; row indices through AtiP / QfiP */
       const int e0 = S.Lp[j], e1 = S.Lp[j + 1];
       /* ---- A' Sigma A, column j: active rows t ascending, lanes over the entries of row t (distinct columns i: no conflicts) ---- */
       if (with_AtSA) {
-        for (int p = Ap[j]; p < Ap[j + 1]; p++) {
+        for (int p = Ap[jo]; p < Ap[jo + 1]; p++) {
           const int t = Ai[p];
           if (!active[t]) continue;
           const double vj = Atss[Ainv[p]];
           for (int q = Atp[t] + lane; q < Atp[t + 1]; q += 64) {
-            const int i = Ati[q];
+            const int i = S.AtiP[q];
             if (i >= j) w[i] += Atss[q] * vj;
           }
           QP_WAVE_SYNC();
         }
       }
-      /* ---- + Q(:, j), + 1 / gamma ---- */
-      for (int k = Qp[j] + lane; k < Qp[j + 1]; k += 64) {
-        const int i = Qi[k];
-        if (i >= j) w[i] = Qx[k] + w[i];
+      /* ---- + Q(:, j) (both triangles are stored: the lower one of the permuted matrix is picked here), + 1 / gamma ---- */
+      for (int k = Qfp[jo] + lane; k < Qfp[jo + 1]; k += 64) {
+        const int i = S.QfiP[k];
+        if (i >= j) w[i] = Qfx[k] + w[i];
       }
       QP_WAVE_SYNC();
       if (proximal && lane == 0) w[j] += 1.0 / gamma;
@@ -167,7 +172,7 @@ QPN double sp_gershgorin(const qpg_view &V, int b, const int n, const SpArrays &
 QPD bool sp_update_pays(int nchange, int nlev, int n) { return (long long)nchange * (long long)nlev * 2 < (long long)n; }
 QPN void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S, const int *up, int n_up, const int *dn, int n_dn) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
+  const int *Atp = V.Atp + (size_t)b * (V.m + 1);
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
   double *w = S.wv; /* wavefront 0's work vector */
   __syncthreads();
@@ -177,10 +182,10 @@ QPN void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S, con
       const int t = update ? up[c] : dn[c - n_up];
       const int q0 = Atp[t], q1 = Atp[t + 1];
       if (q1 <= q0) continue;
-      for (int q = q0 + lane; q < q1; q += 64) w[Ati[q]] = Atss[q];
+      for (int q = q0 + lane; q < q1; q += 64) w[S.AtiP[q]] = Atss[q];
       QP_WAVE_SYNC();
       double alpha = 1.0;
-      int j = Ati[q0]; /* the row's first column (columns ascending) */
+      int j = S.first[t]; /* the row's first column in the factor's numbering: the path starts there */
       while (j >= 0) {
         const int e0 = S.Lp[j], e1 = S.Lp[j + 1];
         const double wj = w[j];
@@ -206,7 +211,10 @@ QPN void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S, con
 }
 
 /* x <- (L D L')^-1 x, in place in HBM */
-QPN void sp_solve(const int n, const SpArrays &S, double *x) {
+QPN void sp_solve(const int n, const SpArrays &S, double *xo) {
+  double *x = S.tmp; /* P b; the result goes back as P' x */
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += QP_T) x[j] = xo[S.perm[j]];
   __syncthreads();
   for (int lev = 0; lev < S.nlev; lev++) { /* forward: a row needs the rows of its structure, which sit in earlier levels */
     for (int c = S.levptr[lev] + (int)threadIdx.x; c < S.levptr[lev + 1]; c += QP_T) {
@@ -229,6 +237,8 @@ QPN void sp_solve(const int n, const SpArrays &S, double *x) {
     }
     if (lev == 0 || sp_level_needs_barrier(S, lev - 1)) __syncthreads();
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += QP_T) xo[S.perm[j]] = x[j];
   __syncthreads();
 }
 

@@ -124,6 +124,9 @@ typedef struct {
   int32_t *sp_levptr, *sp_levcol, *sp_nlev; /* [B][n+1], [B][n], [B]: level sets of the elimination tree */
   double *sp_Lx;            /* [nslots][sp_nnzL] */
   double *sp_wv;            /* [nslots][wavefronts][n] dense work vectors of the factorisation (zero outside of use) */
+  int32_t *sp_perm;         /* [B][n] the factor is that of P H P': perm[new] = old (identity: natural ordering) */
+  int32_t *sp_AtiP, *sp_QfiP, *sp_first; /* [B][nnzA] Ati, [B][nnzQf] Qfi in the factor's numbering; [B][m] first (smallest) such column of every row of A */
+  double *sp_tmp;           /* [nslots][n] the permuted right-hand side of a solve */
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */
   int32_t *queue; /* [64 + QPG_CU_KEYS]: [0] work-queue head; [64 + key] workgroups that have arrived on compute unit `key` in this launch */

@@ -157,6 +157,14 @@ class QpalmBatch:
         self._check(self.L.qpg_batch_sparse_info(self.h, int(b), C.byref(z), C.byref(d)))
         return int(z.value), int(d.value)
 
+    def sparse_perm(self, b=0):
+        """(perm, levels): the ordering of member b's sparse factor (perm[new] = old; identity = natural) and the height of its elimination tree"""
+        n = self.dims[b][0]
+        perm = np.zeros(n, dtype=np.int64)
+        lev = capi.c_int(0)
+        self._check(self.L.qpg_batch_sparse_perm(self.h, int(b), perm.ctypes.data_as(C.POINTER(capi.c_int)), C.byref(lev)))
+        return perm, int(lev.value)
+
     def num_unfinished(self):
         c = capi.c_int(0)
         self._check(self.L.qpg_batch_num_unfinished(self.h, C.byref(c)))

@@ -78,6 +78,9 @@ def run_case(ctx, p, st, warm, oracle_sparse_mode=0):
     o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
     if oracle_sparse_mode:
         o.set_scalar("sparse_mode", oracle_sparse_mode)
+        perm = bt.sparse_perm(0)[0]     # the ordering the engine chose for this factor: the checker factorises the same P H P'
+        if not np.array_equal(perm, np.arange(len(perm))):
+            o.set_perm(perm)
     if warm is not None:
         bt.warm_start(warm[0][None, :], warm[1][None, :])
         o.warm_start(warm[0], warm[1])

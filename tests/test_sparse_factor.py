@@ -23,9 +23,13 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if a.size else 0.0
 
 
-def oracle_sparse(p, **st):
+def oracle_sparse(p, perm=None, **st):
+    """the oracle in its sparse-storage mode; perm: the ordering the ENGINE chose for this QP's factor (QpalmBatch.sparse_perm), so that the
+    checker factorises the same P H P' entry for entry"""
     o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
     o.set_scalar("sparse_mode", 1)
+    if perm is not None and not np.array_equal(perm, np.arange(len(perm))):
+        o.set_perm(perm)
     o.solve()
     return o
 
@@ -75,12 +79,16 @@ def test_oracle_sparse_path_update_equals_the_dense_rank_update():
     assert rel(os_.vec("d"), od.vec("d")) <= 1e-13
 
 
+@pytest.mark.parametrize("ordering", [0, 1])
 @pytest.mark.parametrize("kind,n", [("banded", 90), ("blocks", 96), ("arrow", 60), ("random", 50)])
-def test_sparse_factor_against_the_oracle_and_the_dense_factor(ctx, kind, n):
+def test_sparse_factor_against_the_oracle_and_the_dense_factor(ctx, kind, n, ordering):
+    """ordering 0: the reference's natural ordering; 1: the engine's nested dissection (the oracle then factorises under the same permutation)"""
     p = random_qp(n, 2 * n, seed=7, density_A=0.04, density_M=0.03) if kind == "random" else sparse_qp(n, kind, seed=11)
     res = {}
+    perm = None
     for mode in (0, 1):
         ctx.set_option("sparse_factor", mode)
+        ctx.set_option("sparse_ordering", ordering)
         try:
             bt = QpalmBatch(ctx, [p], ctx.default_settings(**ST))
             bt.solve()
@@ -89,10 +97,17 @@ def test_sparse_factor_against_the_oracle_and_the_dense_factor(ctx, kind, n):
             if mode:
                 nnzL, nbytes = bt.sparse_info(0)
                 assert 0 < nnzL <= n * (n - 1) // 2 and nbytes > 0
+                perm, levels = bt.sparse_perm(0)
+                assert np.array_equal(np.sort(perm), np.arange(p.n)) and 1 <= levels <= p.n
+                if ordering == 0:
+                    assert np.array_equal(perm, np.arange(p.n))
+                elif kind == "banded":
+                    assert levels < p.n // 2        # the chain of 90 columns became a tree
             bt.close()
         finally:
             ctx.set_option("sparse_factor", -1)
-    o = oracle_sparse(p, **ST)
+            ctx.set_option("sparse_ordering", -1)
+    o = oracle_sparse(p, perm, **ST)
     st_, it_, x, y, nref, nfq = res[1]
     assert st_ == o.status_val == 1 and it_ == int(o.info.iter)
     assert (nref, nfq) == (o.counter("n_refactor"), o.counter("n_factor_Q"))
@@ -105,16 +120,49 @@ def test_sparse_factor_batch_of_different_patterns(ctx):
     probs = [sparse_qp(60, "banded", seed=1), sparse_qp(48, "blocks", seed=2), sparse_qp(40, "arrow", seed=3), sparse_qp(33, "banded", seed=4, band=5)]
     ctx.set_option("sparse_factor", 1)
     try:
-        bt = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
-        bt.solve()
-        x, y = bt.solution()
-        for k, p in enumerate(probs):
-            o = oracle_sparse(p, **ST)
-            assert int(bt.info(k).status_val) == o.status_val == 1 and int(bt.info(k).iter) == int(o.info.iter), k
-            assert rel(x[k][:p.n], o.x) <= 1e-9 and rel(y[k][:p.m], o.y) <= 1e-9, k
-        bt.close()
+        for ordering in (0, 1):
+            ctx.set_option("sparse_ordering", ordering)
+            bt = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
+            bt.solve()
+            x, y = bt.solution()
+            for k, p in enumerate(probs):
+                o = oracle_sparse(p, bt.sparse_perm(k)[0], **ST)
+                assert int(bt.info(k).status_val) == o.status_val == 1 and int(bt.info(k).iter) == int(o.info.iter), (ordering, k)
+                assert int(bt.stats(k).n_refactor) == o.counter("n_refactor") and int(bt.stats(k).n_rank1) == o.counter("n_rank1"), (ordering, k)
+                assert rel(x[k][:p.n], o.x) <= 1e-9 and rel(y[k][:p.m], o.y) <= 1e-9, (ordering, k)
+            bt.close()
     finally:
         ctx.set_option("sparse_factor", -1)
+        ctx.set_option("sparse_ordering", -1)
+
+
+@pytest.mark.parametrize("kind,n", [("banded", 3000), ("arrow", 2000), ("blocks", 1600)])
+def test_nested_dissection_makes_chains_into_trees(ctx, kind, n):
+    """the symbolic side alone (no solve): a band's elimination tree under the natural ordering is a chain of n columns; dissected, its
+    height is a few dozen columns at a modest price in fill; a block-diagonal pattern is left as it is.  The automatic choice
+    (sparse_ordering = -1) takes the dissection for the chain and the natural ordering for the forest."""
+    p = sparse_qp(n, kind, seed=2)
+    out = {}
+    ctx.set_option("sparse_factor", 1)
+    try:
+        for ordering in (0, 1, -1):
+            ctx.set_option("sparse_ordering", ordering)
+            bt = QpalmBatch(ctx, [p], ctx.default_settings(**ST))
+            perm, levels = bt.sparse_perm(0)
+            assert np.array_equal(np.sort(perm), np.arange(p.n))
+            out[ordering] = (levels, bt.sparse_info(0)[0], perm)
+            bt.close()
+    finally:
+        ctx.set_option("sparse_factor", -1)
+        ctx.set_option("sparse_ordering", -1)
+    print(kind, n, {k: v[:2] for k, v in out.items()})
+    if kind == "blocks":
+        assert out[1][0] == out[0][0] == 8 and out[1][1] == out[0][1]
+        assert np.array_equal(out[-1][2], np.arange(p.n))
+    else:
+        assert out[0][0] == p.n                                  # one column per level
+        assert out[1][0] <= 120 and out[1][1] <= 3 * out[0][1] + p.n
+        assert out[-1][0] == out[1][0] and np.array_equal(out[-1][2], out[1][2])
 
 
 def test_sparse_factor_refuses_what_it_does_not_cover(ctx):
@@ -152,27 +200,33 @@ def _kkt_check(p, x, y, tol=1e-5):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,n", [("blocks", 100000), ("banded", 20000), ("arrow", 20000)])
-def test_sparse_factor_at_size(kind, n):
-    """beyond any dense panel (qpg_batch_create refused more than 8192 rows through round 4): selected automatically"""
+@pytest.mark.parametrize("kind,n,ordering", [("blocks", 100000, -1), ("banded", 20000, -1), ("arrow", 20000, -1), ("banded", 20000, 0), ("banded", 100000, -1)])
+def test_sparse_factor_at_size(kind, n, ordering):
+    """beyond any dense panel (qpg_batch_create refused more than 8192 rows through round 4): selected automatically.  ordering -1: the
+    library's choice (nested dissection for the two chains, natural for the forest); 0: the reference's natural ordering on the chain"""
     import time
     from qpalm_amd.solver import Context
     ctx = Context(0)
+    ctx.set_option("sparse_ordering", ordering)
     p = sparse_qp(n, kind, seed=21)
     bt = QpalmBatch(ctx, [p], ctx.default_settings(**ST))
     nnzL, nbytes = bt.sparse_info(0)
+    perm, levels = bt.sparse_perm(0)
+    assert (levels <= 100) if (ordering != 0 or kind == "blocks") else (levels == p.n)
     t0 = time.perf_counter()
     bt.solve()
     dt = time.perf_counter() - t0
     x, y = bt.solution()
     info, s = bt.info(0), bt.stats(0)
-    print("sparse factor, %s n = %d m = %d: nnz(L) = %d (dense triangle %.3g), device block %.1f MB, %d iterations, %d + %d factorisations, %.2f s" % (
-        kind, p.n, p.m, nnzL, 0.5 * p.n * p.n, nbytes / 2 ** 20, int(info.iter), int(s.n_refactor), int(s.n_factor_Q), dt))
+    print("sparse factor, %s n = %d m = %d, ordering %d: %d levels, nnz(L) = %d (dense triangle %.3g), device block %.1f MB, %d iterations, %d + %d factorisations, %d path updates, %.2f s" % (
+        kind, p.n, p.m, ordering, levels, nnzL, 0.5 * p.n * p.n, nbytes / 2 ** 20, int(info.iter), int(s.n_refactor), int(s.n_factor_Q), int(s.n_rank1), dt))
     assert int(info.status_val) == 1
     assert nnzL <= 40 * p.n and nbytes <= 200 * 8 * (nnzL + 40 * p.n)      # memory proportional to nnz(L) (+ O(n) work vectors), nowhere near n^2
     _kkt_check(p, x[0], y[0])
-    o = oracle_sparse(p, **ST)
-    assert o.status_val == 1 and int(info.iter) == int(o.info.iter) and int(s.n_refactor) == o.counter("n_refactor")
+    t0 = time.perf_counter()
+    o = oracle_sparse(p, perm, **ST)
+    print("  the oracle (one CPU core, sparse storage, same ordering): %.2f s" % (time.perf_counter() - t0))
+    assert o.status_val == 1 and int(info.iter) == int(o.info.iter) and int(s.n_refactor) == o.counter("n_refactor") and int(s.n_rank1) == o.counter("n_rank1")
     assert rel(x[0], o.x) <= 1e-8 and rel(y[0], o.y) <= 1e-8
     bt.close()
 
@@ -218,6 +272,7 @@ def test_large_sparse_qps_files_through_the_reader(tmp_path):
     from qpalm_amd.qps import read_qps, solve_qps_files
     from qpalm_amd.solver import Context
     ctx = Context(0)
+    ctx.set_option("sparse_ordering", 0)     # the reference's natural ordering (the batches are made inside solve_qps_files: the oracle below is not told a permutation)
     gens = [("banded12k", sparse_qp(12000, "banded", seed=31)), ("blocks30k", sparse_qp(30000, "blocks", seed=32)), ("small", sparse_qp(40, "banded", seed=33))]
     paths = []
     for name, p in gens:

@@ -1,7 +1,8 @@
 """Randomised parity fuzzing (cases: tests/fuzz_cases.py), the engine against the oracle, judged by the rule of tests/test_fuzz_seeds.py
 (judge_case: status and iteration count exact, x to 1e-8, y to max(1e-8, 100 sigma dx) -- unless the oracle's own outcome
 depends on its floating-point contraction, then status among the variants' and objectives to 10 x eps).  TEST TOOL (uses oracle/): python tools/evidence/fuzz_parity.py <seed> <cases> [hip|emu] [n_lo n_hi] [key=value ...]
-(key=value pairs force settings, e.g. factorization_method=0 sigma_init=1e3; sparse=1: the engine's sparse factor against the oracle's sparse-storage mode)."""
+(key=value pairs force settings, e.g. factorization_method=0 sigma_init=1e3; sparse=1: the engine's sparse factor against the oracle's sparse-storage mode,
+ordering=1 with it: under the engine's nested-dissection ordering)."""
 import os
 import sys
 import time
@@ -23,8 +24,11 @@ seed = int(pos[0]) if len(pos) > 0 else 0
 N = int(pos[1]) if len(pos) > 1 else 100
 NLO, NHI = (int(pos[3]), int(pos[4])) if len(pos) > 4 else (2, 70)   # range of n (m up to 1.7 n)
 sparse = int(force.pop("sparse", 0))
+ordering = force.pop("ordering", None)   # with sparse=1: 0 natural, 1 nested dissection (default: the library's automatic choice)
 if sparse:
     ctx.set_option("sparse_factor", 1)
+    if ordering is not None:
+        ctx.set_option("sparse_ordering", int(ordering))
     force.update(dict(factorization_method=1, enable_dual_termination=0))
 worst_dy_ratio = 0.0   # largest dy / derived bound among the cases that needed more than 1e-8 on y
 bad = 0    # fails the rule (or an exception)
