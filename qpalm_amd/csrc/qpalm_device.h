@@ -192,6 +192,10 @@ QPD int wave_isum(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+QPD int wave_imax(int v) {
+  for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = (u > v) ? u : v; }
+  return v;
+}
 QPD int wave_imin(int v) {
   for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = (u < v) ? u : v; }
   return v;

@@ -42,7 +42,7 @@ QPD SpArrays sp_arrays(const qpg_view &V, int b, int slot, double *Dg) {
   s.levptr = V.sp_levptr + (size_t)b * (V.n + 1); s.levcol = V.sp_levcol + (size_t)b * V.n;
   s.perm = V.sp_perm + (size_t)b * V.n; s.AtiP = V.sp_AtiP + (size_t)b * V.nnzA; s.QfiP = V.sp_QfiP + (size_t)b * V.nnzQf; s.first = V.sp_first + (size_t)b * V.m;
   s.nlev = V.sp_nlev[b];
-  s.Lx = V.sp_Lx + (size_t)slot * V.sp_nnzL; s.Dg = Dg; s.wv = V.sp_wv + (size_t)slot * QP_NW * V.n; s.tmp = V.sp_tmp + (size_t)slot * V.n;
+  s.Lx = V.sp_Lx + (size_t)slot * V.sp_nnzL; s.Dg = Dg; s.wv = V.sp_wv + (size_t)slot * QP_NW * V.sp_gpw * V.n; s.tmp = V.sp_tmp + (size_t)slot * V.n;
   return s;
 }
 
@@ -54,7 +54,12 @@ QPD bool sp_level_needs_barrier(const SpArrays &S, int lev) {
 /* H = Q (+ A' Sigma_act A) (+ I / gamma) assembled column by column and factorised in the same pass (see the header).
  * Q_only_values: the second resident factor LD_Q of the dual objective is not supported in sparse mode (qpg_batch_create refuses). */
 QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, bool with_AtSA, bool proximal, double gamma) {
+  /* a column per GROUP of lanes: the columns of a sparse factor are short (a band: half a dozen entries), so a wavefront takes gpw = 1, 2
+   * or 4 columns of the level at a time (16 lanes each at 4) and a 512-thread workgroup up to 32 -- every step of a column is a chain of
+   * dependent HBM round trips, the groups' chains overlap.  Loops run to the wavefront's longest trip count with the other groups
+   * masked off, so that the wavefront-level synchronisation points are met by every lane. */
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gpw = V.sp_gpw, spg = 64 / gpw, gl = lane & (spg - 1), grp = wid * gpw + lane / spg, ngrp = QP_NW * gpw;
   const int *Ap = V.Ap + (size_t)b * (V.n + 1), *Ai = V.Ai + (size_t)b * V.nnzA;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1);
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
@@ -62,57 +67,77 @@ QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, boo
   const int *Qfp = V.Qfp + (size_t)b * (V.n + 1);
   const double *Qfx = V.Qfx + (size_t)b * V.nnzQf;
   const int *active = V.active + (size_t)b * V.m;
-  double *w = S.wv + (size_t)wid * n; /* this wavefront's work vector: zero on entry, zero again when the column is done */
+  double *w = S.wv + (size_t)grp * n; /* this group's work vector: zero on entry, zero again when the column is done */
   __syncthreads();
   for (int lev = 0; lev < S.nlev; lev++) {
     const int c0 = S.levptr[lev], c1 = S.levptr[lev + 1];
-    for (int c = c0 + wid; c < c1; c += QP_NW) {
-      const int j = S.levcol[c];
-      const int jo = S.perm[j]; /* column j of P H P' is column perm[j] of H; row indices through AtiP / QfiP */
-      const int e0 = S.Lp[j], e1 = S.Lp[j + 1];
+    for (int cw = c0 + wid * gpw; cw < c1; cw += ngrp) { /* (the same for the lanes of a wavefront) */
+      const int c = cw + lane / spg;
+      const bool on = c < c1;
+      const int j = on ? S.levcol[c] : 0;
+      const int jo = on ? S.perm[j] : 0; /* column j of P H P' is column perm[j] of H; row indices through AtiP / QfiP */
+      const int e0 = on ? S.Lp[j] : 0, e1 = on ? S.Lp[j + 1] : 0;
       /* ---- A' Sigma A, column j: active rows t ascending, lanes over the entries of row t (distinct columns i: no conflicts) ---- */
       if (with_AtSA) {
-        for (int p = Ap[jo]; p < Ap[jo + 1]; p++) {
-          const int t = Ai[p];
-          if (!active[t]) continue;
-          const double vj = Atss[Ainv[p]];
-          for (int q = Atp[t] + lane; q < Atp[t + 1]; q += 64) {
-            const int i = S.AtiP[q];
-            if (i >= j) w[i] += Atss[q] * vj;
+        const int p0 = on ? Ap[jo] : 0, p1 = on ? Ap[jo + 1] : 0;
+        const int np = wave_imax(p1 - p0);
+        for (int pp = 0; pp < np; pp++) {
+          const int p = p0 + pp;
+          int t = 0;
+          bool act = p < p1;
+          if (act) { t = Ai[p]; act = active[t] != 0; }
+          const double vj = act ? Atss[Ainv[p]] : 0.0;
+          const int q0 = act ? Atp[t] : 0, q1 = act ? Atp[t + 1] : 0;
+          const int nq = wave_imax(q1 - q0);
+          for (int qq = gl; qq < nq; qq += spg) {
+            const int q = q0 + qq;
+            if (q < q1) {
+              const int i = S.AtiP[q];
+              if (i >= j) w[i] += Atss[q] * vj;
+            }
           }
           QP_WAVE_SYNC();
         }
       }
       /* ---- + Q(:, j) (both triangles are stored: the lower one of the permuted matrix is picked here), + 1 / gamma ---- */
-      for (int k = Qfp[jo] + lane; k < Qfp[jo + 1]; k += 64) {
-        const int i = S.QfiP[k];
-        if (i >= j) w[i] = Qfx[k] + w[i];
+      {
+        const int k0 = on ? Qfp[jo] : 0, k1 = on ? Qfp[jo + 1] : 0;
+        for (int k = k0 + gl; k < k1; k += spg) {
+          const int i = S.QfiP[k];
+          if (i >= j) w[i] = Qfx[k] + w[i];
+        }
       }
       QP_WAVE_SYNC();
-      if (proximal && lane == 0) w[j] += 1.0 / gamma;
+      if (on && proximal && gl == 0) w[j] += 1.0 / gamma;
       QP_WAVE_SYNC();
       /* ---- left-looking updates: every column k < j with l_jk != 0, ascending ---- */
-      for (int r = S.Rp[j]; r < S.Rp[j + 1]; r++) {
-        const int k = S.Rk[r], pos = S.Rpos[r];
-        const double ljk = S.Lx[pos];
-        const double mk = ljk * S.Dg[k];
-        if (lane == 0) w[j] = QP_FMA(-ljk, mk, w[j]);
-        const int k1 = S.Lp[k + 1];
-        for (int e = pos + 1 + lane; e < k1; e += 64) { /* rows below j of column k: they all belong to column j's pattern */
-          const int i = S.Li[e];
-          w[i] = QP_FMA(-S.Lx[e], mk, w[i]);
+      {
+        const int r0 = on ? S.Rp[j] : 0, r1 = on ? S.Rp[j + 1] : 0;
+        const int nr = wave_imax(r1 - r0);
+        for (int rr = 0; rr < nr; rr++) {
+          const int r = r0 + rr;
+          const bool has = r < r1;
+          const int k = has ? S.Rk[r] : 0, pos = has ? S.Rpos[r] : 0;
+          const double ljk = has ? S.Lx[pos] : 0.0;
+          const double mk = has ? ljk * S.Dg[k] : 0.0;
+          if (has && gl == 0) w[j] = QP_FMA(-ljk, mk, w[j]);
+          const int k1 = has ? S.Lp[k + 1] : 0;
+          for (int e = pos + 1 + gl; e < k1; e += spg) { /* rows below j of column k: they all belong to column j's pattern */
+            const int i = S.Li[e];
+            w[i] = QP_FMA(-S.Lx[e], mk, w[i]);
+          }
+          QP_WAVE_SYNC();
         }
-        QP_WAVE_SYNC();
       }
       /* ---- pivot and column; the work vector goes back to zero ---- */
-      const double dj = w[j];
+      const double dj = on ? w[j] : 1.0;
       QP_WAVE_SYNC();
-      for (int e = e0 + lane; e < e1; e += 64) {
+      for (int e = e0 + gl; e < e1; e += spg) {
         const int i = S.Li[e];
         S.Lx[e] = w[i] / dj;
         w[i] = 0.0;
       }
-      if (lane == 0) { S.Dg[j] = dj; w[j] = 0.0; }
+      if (on && gl == 0) { S.Dg[j] = dj; w[j] = 0.0; }
       QP_WAVE_SYNC();
     }
     /* a run of one-column levels (a chain of the tree) is wavefront 0's alone: no workgroup barrier inside the run */

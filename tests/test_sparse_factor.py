@@ -231,6 +231,39 @@ def test_sparse_factor_at_size(kind, n, ordering):
     bt.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [("banded", 2000), ("blocks", 2000)])
+def test_sparse_batch_throughput(kind, n):
+    """what the sparse mode is for on this hardware: MANY sparse QPs at once, one workgroup each (a single one runs at the latency of its
+    tree: test_sparse_factor_at_size).  2048 QPs with n = 2000 (64 distinct ones, repeated); a sample against the oracle under the same
+    ordering; the oracle's time on one core printed beside it (profiles/r05)."""
+    import time
+    from qpalm_amd.solver import Context
+    ctx = Context(0)
+    ctx.set_option("sparse_factor", 1)
+    distinct = [sparse_qp(n, kind, seed=700 + k) for k in range(64)]
+    probs = [distinct[k % 64] for k in range(2048)]
+    bt = QpalmBatch(ctx, probs, ctx.default_settings(**ST))
+    bt.solve()                                      # (warm-up: first launch of the kernel)
+    bt.warm_start(None, None)
+    t0 = time.perf_counter()
+    bt.solve()
+    dt = time.perf_counter() - t0
+    x, y = bt.solution()
+    assert all(int(bt.info(k).status_val) == 1 for k in range(len(probs)))
+    t_or = 0.0
+    for k in range(0, 64, 8):
+        t1 = time.perf_counter()
+        o = oracle_sparse(distinct[k], bt.sparse_perm(k)[0], **ST)
+        t_or += time.perf_counter() - t1
+        for kk in (k, k + 64 * 31):
+            assert int(bt.info(kk).iter) == int(o.info.iter) and rel(x[kk], o.x) <= 1e-8 and rel(y[kk], o.y) <= 1e-8, kk
+    nnzL, nbytes = bt.sparse_info(0)
+    print("sparse batch, %s n = %d: %d QPs in %.3f s = %.0f QP/s (%d levels, nnz(L) = %d, device block %.0f MB); the oracle on one core, same ordering: %.1f QP/s" % (
+        kind, n, len(probs), dt, len(probs) / dt, bt.sparse_perm(0)[1], nnzL, nbytes / 2 ** 20, 8 / t_or))
+    bt.close()
+
+
 def write_free_qps(path, p, name="SPARSEQP"):
     """a QP of qpalm_amd.problems as a free-format QPS file: every row an L row with RHS = bmax and RANGES = bmax - bmin, every variable FR
     (the reader then appends no bound rows), QUADOBJ = the lower triangle"""
