@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/$R/final
 mkdir -p $OUT
 cd $REPO
-timeout 900 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
+timeout 1800 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel trace (own run) and the PMC passes (separate runs, counters only), all of the default bench command
@@ -28,6 +28,7 @@ timeout 1200 python bench.py --traffic-json $OUT/k_solve_pmc_traffic.json > $OUT
 timeout 600 python bench.py --batch 512 --no-cpu --no-mpc > $OUT/bench_b512.json 2>> $OUT/bench_default.err
 timeout 600 python bench.py --workload mpc-160 --steps 5 > $OUT/bench_mpc160.json 2>> $OUT/bench_default.err
 timeout 600 python bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt.json 2>> $OUT/bench_default.err
+timeout 600 python bench.py --workload mpc-160 --steps 5 --small-workgroups 3 --no-cpu > $OUT/bench_mpc160_256_thread_instance.json 2>> $OUT/bench_default.err
 timeout 600 python bench.py --sweep-ranks 32 --no-cpu --no-mpc > $OUT/bench_sweep_ranks_32.json 2>> $OUT/bench_default.err
 bash tools/evidence/phase_traffic.sh $R/final/phase_traffic > $OUT/phase_traffic.log 2>&1
 timeout 300 python tools/evidence/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_probe.txt 2>> $OUT/bench_default.err
@@ -39,7 +40,7 @@ QPALM_COOP_PROFILE=1 timeout 900 python -m pytest tests/test_coop.py -q -m gpu -
 mkdir -p $REPO/gpurun_out/$R/batch
 for b in 16 64 128 256; do timeout 300 python bench.py --batch $b --steps 3 --warmup 1 --no-cpu --no-mpc > $REPO/gpurun_out/$R/batch/bench_b$b.json 2>> $OUT/bench_default.err; done
 # the sparse factor at size
-timeout 900 python -m pytest tests/test_sparse_factor.py -q -m gpu -s > $OUT/sparse_factor_at_size.txt 2>&1
+timeout 1200 python -m pytest tests/test_sparse_factor.py -q -m gpu -s > $OUT/sparse_factor_at_size.txt 2>&1
 timeout 300 tools/evidence/sload_coherence_test > $OUT/sload_coherence.txt 2>&1
 timeout 200 tools/evidence/host_alloc_probe > $OUT/host_alloc_probe.txt 2>&1
 ls -la $OUT
