@@ -18,12 +18,29 @@
 #include <type_traits>
 
 #ifdef QPALM_EMU
+/* cross-workgroup hand-off (co_updown_persist): the emulator runs the workgroups of a grid one after the other, in order */
+#define QP_FLAG_LOAD(p) (*(volatile int *)(p))
+#define QP_FLAG_STORE(p, v) (*(volatile int *)(p) = (v))
+#define QP_RELEASE_AGENT() do { } while (0)
+#define QP_ACQUIRE_AGENT() do { } while (0)
+#define QP_DRAIN_VMEM() do { } while (0)
+#define QP_SLEEP() do { } while (0)
 #define QP_WAVE_SYNC() emu_wave_sync()
 #define QP_LDS_VBASE(p) (p)
 #define QP_SCHED_BARRIER() do { } while (0)
 #define QP_SETPRIO(p) do { } while (0)
 #define QP_DRAIN_LDS() do { } while (0)
 #else
+/* cross-workgroup hand-off inside one launch (co_updown_persist): payload by plain stores, every storing wavefront drains, ONE lane
+ * releases at agent scope (write-back of the XCD's L2), drains again (the compiler may drop the fence's own wait) and stores the flag
+ * with an agent-scope atomic; the consumer polls that ONE word relaxed, acquires ONCE at agent scope (drops its CU's stale L1 lines),
+ * drains, and the workgroup barrier behind it lets the other wavefronts load plainly. */
+#define QP_FLAG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define QP_FLAG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define QP_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define QP_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define QP_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define QP_SLEEP() __builtin_amdgcn_s_sleep(2)
 #define QP_SETPRIO(p) __builtin_amdgcn_s_setprio(p) /* issue priority of a wavefront on its SIMD */
 #define QP_DRAIN_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory") /* diagnostic stamps: every LDS operation issued so far has returned */
 /* keeps the scheduler from hoisting a whole unrolled loop's LDS reads to the top (register blow-up) */
@@ -2037,6 +2054,141 @@ QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, doubl
 #pragma unroll
       for (int r = 0; r < K; r++) if (r < kk) Wst[(size_t)r * n + i] = w[r];
     }
+}
+
+/* --------------------------------------------------------------------------------------------
+ * The same update as ONE launch (coop_updates = 2; VERDICT round 4, item 4: "a sweep one persistent launch").  A chain of
+ * co_updown_block launches pays a kernel boundary per 32 columns (157 at n = 5000: 4.9 ms for a sweep that moves 200 MB) and every
+ * workgroup repeats the block's recurrence.  Here a workgroup OWNS 128 rows of the panel for the whole sweep -- one row per thread of
+ * two wavefronts, the row's kk running values in registers from the first block to the last instead of through HBM at every block --
+ * and the four diagonal blocks inside those rows: it applies the tables of the blocks in front of its rows as their owners publish
+ * them, then runs the recurrence of its own blocks (updown_big_panel, once per block in the whole grid), publishes each table
+ * ((-w, -gamma) per column and rank + the running alpha: 8.4 KB) and a counter, and applies it to its remaining rows.  The only
+ * data that crosses workgroups are the tables: L, D and the running vectors of a row are touched by its owner alone.
+ * Hand-off: QP_RELEASE_AGENT / QP_ACQUIRE_AGENT above; one counter (flags[0] = blocks published so far, set to the first block
+ * by the init launch), polled by one lane with a bounded spin (flags[1] != 0: gave up -- the host reports it, nothing hangs); the
+ * grid is one workgroup per 128 rows (at most 64: all resident), workgroup g waits only for workgroups < g.
+ * The arithmetic per entry is co_updown_block's: bit-identical factors.
+ * ------------------------------------------------------------------------------------------- */
+#define CO_UD_TAB(K) (QP_UNB * (K) * 2 + 2 * (K)) /* doubles per published table: the block's (-w, -gamma) pairs, then alpha and 1 / alpha per rank */
+template <int K>
+QPD void co_updown_persist(const int n, const int ld, double *L, double *Dg, const double *Wst, const double *hst, double *tab, int *flags,
+                           const int r0, const int kk, const int n_up, char *lds, const int wg, QpShared &S) {
+  typedef UpdownBigLds<K> LdsT;
+  LdsT QP_LDS_AS &U = *QP_LDS_ARG(LdsT, lds);
+  double QP_LDS_AS *wd = (double QP_LDS_AS *)(QP_LDS_ARG(char, lds) + ((sizeof(LdsT) + 15) & ~(size_t)15)); /* [NB][K]: running values of a diagonal block's rows */
+  double QP_LDS_AS *cw = (double QP_LDS_AS *)&U.cwg[0][0][0];
+  const int NB = QP_UNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int R0 = wg * CO_UD_ROWS, R1 = (R0 + CO_UD_ROWS < n) ? R0 + CO_UD_ROWS : n;
+  if (R0 >= n) return;
+  const int bstart = (int)hst[CO_UD_JMIN] / NB; /* the update vectors are zero above their first entry: blocks in front of it are not touched */
+  const int bown0 = R0 / NB, bown1 = (R1 + NB - 1) / NB; /* my diagonal blocks */
+  if (bown1 <= bstart) return;
+  const int rt = tid - CO_UD_FIRST;
+  const int i = R0 + rt;
+  const bool live = rt >= 0 && rt < CO_UD_ROWS && i < n;
+  double w[K], l[NB];
+#pragma unroll
+  for (int r = 0; r < K; r++) w[r] = (live && r < kk) ? Wst[(size_t)r * n + i] : 0.0;
+  auto apply_rows = [&](const int J) QP_ALWAYS_INLINE { /* table in U.cwg, the row's 32 entries of block column J in l */
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+#pragma unroll
+      for (int r = 0; r < K; r++) {
+        if (r >= kk) break;
+        w[r] = QP_FMA(U.cwg[c][r][0], l[c], w[r]);
+        l[c] = QP_FMA(U.cwg[c][r][1], w[r], l[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NB; c++) L[(size_t)(J + c) * ld + i] = l[c];
+  };
+  /* ---- the blocks in front of my rows: their tables, as they are published ---- */
+  int next = bstart;
+  while (next < bown0) {
+    if (tid == 0) {
+      int r = QP_FLAG_LOAD(flags);
+      for (unsigned spins = 0; r <= next && spins < (1u << 22); spins++) { QP_SLEEP(); r = QP_FLAG_LOAD(flags); }
+      if (r <= next) { QP_FLAG_STORE(flags + 1, 1 + wg); r = -1; }
+      QP_ACQUIRE_AGENT();
+      QP_DRAIN_VMEM();
+      S.ired[0][3] = r;
+    }
+    __syncthreads();
+    int upto = S.ired[0][3];
+    if (upto < 0) return; /* a producer never arrived (flags[1] says who gave up) */
+    upto = (upto < bown0) ? upto : bown0;
+    for (int b = next; b < upto; b++) {
+      const int J = b * NB;
+      const double *T = tab + (size_t)b * CO_UD_TAB(K);
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) l[c] = L[(size_t)(J + c) * ld + i];
+      }
+      for (int e = tid; e < NB * K * 2; e += QP_T) cw[e] = T[e];
+      __syncthreads();
+      if (live) apply_rows(J);
+      __syncthreads();
+    }
+    next = upto;
+  }
+  /* ---- my own blocks ---- */
+  double alpha = 1.0, ialpha = 1.0;
+  bool have_alpha = false;
+  for (int b = (bown0 > bstart) ? bown0 : bstart; b < bown1; b++) {
+    const int J = b * NB, jb = (n - J < NB) ? (n - J) : NB;
+    for (int e = tid; e < jb * jb; e += QP_T) {
+      const int c1 = e / jb, c = e % jb;
+      if (c > c1) U.Ld[c][c1] = L[(size_t)(J + c1) * ld + (J + c)];
+    }
+    if (tid < jb) U.dd[tid] = Dg[J + tid];
+    if (live && i >= J && i < J + jb) {
+#pragma unroll
+      for (int r = 0; r < K; r++) wd[(i - J) * K + r] = w[r];
+    }
+    const bool below = live && i >= J + jb; /* rows of my chunk under the block (full blocks only) */
+    if (below) {
+#pragma unroll
+      for (int c = 0; c < NB; c++) l[c] = L[(size_t)(J + c) * ld + i]; /* in flight under the recurrence */
+    }
+    __syncthreads();
+    if (wid == 0) {
+      double wrow[K];
+#pragma unroll
+      for (int r = 0; r < K; r++) wrow[r] = (lane < jb && r < kk) ? wd[lane * K + r] : 0.0;
+      double dreg = (lane < jb) ? U.dd[lane] : 1.0;
+      const int rl = QP_PANEL_DPP ? (lane & (K - 1)) : lane;
+      if (!have_alpha) { /* the carry of the block in front of mine arrived with its table */
+        if (b > bstart) {
+          const double *T = tab + (size_t)(b - 1) * CO_UD_TAB(K) + NB * K * 2;
+          alpha = (rl < K) ? T[rl] : 1.0; ialpha = (rl < K) ? T[K + rl] : 1.0;
+        }
+        have_alpha = true;
+      }
+      const int grank = r0 + rl;
+      const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
+      updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha);
+      QP_WAVE_SYNC();
+      if (lane < jb) Dg[J + lane] = dreg;
+#pragma unroll 1
+      for (int c = 0; c < jb; c++)
+        if (lane > c && lane < jb) L[(size_t)(J + c) * ld + (J + lane)] = U.Ld[lane][c];
+      if (R1 < n) { /* somebody owns rows under mine: publish */
+        double *T = tab + (size_t)b * CO_UD_TAB(K);
+        for (int e = lane; e < NB * K * 2; e += 64) T[e] = cw[e];
+        if (lane < K) { T[NB * K * 2 + lane] = alpha; T[NB * K * 2 + K + lane] = ialpha; }
+        QP_DRAIN_VMEM();
+        if (lane == 0) {
+          QP_RELEASE_AGENT();
+          QP_DRAIN_VMEM();
+          QP_FLAG_STORE(flags, b + 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (below) apply_rows(J);
+    __syncthreads();
+  }
 }
 
 #endif

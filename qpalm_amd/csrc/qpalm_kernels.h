@@ -560,6 +560,21 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_updown(qpg_view V, int
     }
   }
   else co_updown_block<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, J, r0, kk, n_up, lds, (int)blockIdx.x, (int)gridDim.x);
+  if (phase == 1 && blockIdx.x == 0 && threadIdx.x == 0 && V.co_flags) V.co_flags[(size_t)b * 4] = (int)hst[CO_UD_JMIN] / QP_UNB; /* the persistent sweep's counter: blocks published so far */
+}
+/* ... and the whole sweep in ONE launch after phases 0 and 1 (co_updown_persist: one workgroup per 128 rows, at most 64 of them on the
+ * chip, so no occupancy attribute: the row's 32 entries and 16 running values stay in registers next to the recurrence's) */
+__global__ __launch_bounds__(QP_T) void k_co_sweep(qpg_view V, int b, int slot, int r0) {
+  __shared__ QpShared S;
+  char *lds = QP_DYN_LDS();
+  const QpArrays a = qp_arrays(V, b);
+  const int n = a.n;
+  const int la = V.sc[b].pend_la, n_up = (la == 2) ? V.sc[b].nb_enter : V.sc[b].pend_nchange, n_dn = (la == 2) ? V.sc[b].nb_leave : 0;
+  if (r0 >= n_up + n_dn) return;
+  const int kk = (n_up + n_dn - r0 < QPG_KMAX) ? (n_up + n_dn - r0) : QPG_KMAX;
+  double *L = co_slot_L(V, slot, 0), *Dg = co_slot_D(V, slot, 0), *Wst = V.Wst + (size_t)slot * V.wst_stride;
+  const double *hst = Wst + (size_t)QPG_KMAX * V.nfac + QPG_DUMMY;
+  co_updown_persist<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, V.co_tab + (size_t)b * V.co_tab_stride, V.co_flags + (size_t)b * 4, r0, kk, n_up, lds, (int)blockIdx.x, S);
 }
 
 /* Diagnostic (tools/evidence/sweep_probe.py): every resident workgroup factorises Q + I/gamma of its QP and then applies `reps` times a

@@ -124,6 +124,9 @@ typedef struct {
   int32_t *sp_levptr, *sp_levcol, *sp_nlev; /* [B][n+1], [B][n], [B]: level sets of the elimination tree */
   double *sp_Lx;            /* [nslots][sp_nnzL] */
   double *sp_wv;            /* [nslots][wavefronts][n] dense work vectors of the factorisation (zero outside of use) */
+  double *co_tab;           /* coop mode, persistent update sweep: [B][co_tab_stride] the tables the owners of the diagonal blocks publish */
+  int32_t *co_flags;        /* [B][4]: [0] blocks published so far, [1] != 0: a workgroup gave up waiting */
+  int64_t co_tab_stride;
   int32_t *sp_perm;         /* [B][n] the factor is that of P H P': perm[new] = old (identity: natural ordering) */
   int32_t *sp_AtiP, *sp_QfiP, *sp_first; /* [B][nnzA] Ati, [B][nnzQf] Qfi in the factor's numbering; [B][m] first (smallest) such column of every row of A */
   double *sp_tmp;           /* [nslots][n] the permuted right-hand side of a solve */

@@ -66,6 +66,30 @@ def test_coop_matches_single_workgroup_and_oracle(ctx, extra):
         assert np.array_equal(b2.ivec("active", k), o.ivec("active"))
 
 
+def test_coop_update_sweep_in_one_launch_equals_the_chain_of_launches(ctx):
+    """coop_updates = 2 (default): a rank-update sweep is ONE launch, a workgroup owns 128 rows for the whole sweep and the owners of the
+    diagonal blocks hand their tables down through a counter; = 1: one launch per 32-column block.  Same arithmetic per entry: the two
+    must agree BIT FOR BIT (x, y and the counts), and with the one-workgroup path to rounding.  Sizes: three / eight row chunks, the last
+    one ragged; more than 16 ranks in some iterations (two sweeps)."""
+    n, m = sizes(ctx, (300, 420), (1000, 2000))
+    p = random_qp(n, m, seed=4242, density_A=0.01 if n >= 400 else 4.0 / n, density_M=0.005 if n >= 400 else 2.0 / n)
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    res = {}
+    try:
+        for cu in (2, 1):
+            ctx.set_option("coop_updates", cu)
+            bt, x, y, _ = _solve(ctx, [p], st, coop=True)
+            res[cu] = (int(bt.info(0).status_val), int(bt.info(0).iter), int(bt.stats(0).n_rank1), int(bt.stats(0).n_refactor), x[0].copy(), y[0].copy())
+            bt.close()
+    finally:
+        ctx.set_option("coop_updates", 2)
+    assert res[2][:4] == res[1][:4] and res[2][0] == 1 and res[2][2] > 0
+    assert np.array_equal(res[2][4], res[1][4]) and np.array_equal(res[2][5], res[1][5])
+    b1, x1, y1, _ = _solve(ctx, [p], st, coop=False)
+    assert int(b1.info(0).iter) == res[2][1] and rel(res[2][4], x1[0]) <= RTOL and rel(res[2][5], y1[0]) <= RTOL
+    b1.close()
+
+
 def test_coop_members_of_different_sizes_and_repeated_solves(ctx):
     """two QPs of different sizes in one coop batch, solved three times (on the GPU the launch chains of each member are recorded
     during the second solve and replayed as graphs in the third): every solve against the oracle"""
