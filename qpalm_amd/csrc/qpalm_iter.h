@@ -499,10 +499,10 @@ QPPH double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, 
   /* The sort buffer is LDS whenever 12 bytes per (power-of-two padded) breakpoint fit, else HBM.  The
    * code is instantiated once per case so that the pointers have a KNOWN address space: a run-time
    * select between the two makes them generic, and flat accesses to LDS made this phase 10x slower. */
-  const bool in_lds = ((size_t)P2 * 12 <= (size_t)V.lds_bytes);
+  const bool in_lds = !V.ls_hbm && ((size_t)P2 * 12 <= (size_t)V.lds_bytes);
   int nL = 0, mypos = 0x7fffffff;
   double mytau = 0.0, ta = 0.0, tb = 0.0;
-  auto sort_and_scan = [&](auto keys, auto idx) QP_ALWAYS_INLINE {
+  auto sort_and_scan = [&](auto keys, auto idx, auto tiled) QP_ALWAYS_INLINE {
   {
     int base = 0;
     for (int e0 = 0; e0 < 2 * m; e0 += QP_T) {
@@ -532,6 +532,51 @@ QPPH double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, 
   __syncthreads();
   if (tid == 0) { const long long t = QP_CLOCK(); I.s.ticks_dbg[14] += t - tl0; tl0 = t; } /* 14: breakpoints + compaction */
   /* bitonic sort ascending by (key, idx) */
+  if (decltype(tiled)::value) {
+    /* the buffer is in HBM (more than lds_bytes / 12 breakpoints: m > 3200 or so): every compare-exchange distance below the tile size
+     * stays inside a tile, so a tile (as many entries as the LDS holds) is loaded once, taken through ALL those steps in LDS and
+     * stored once -- for 131 072 breakpoints 21 passes over the buffer instead of 153.  The network, hence the result, is the same. */
+    int TS = 2;
+    while ((size_t)(TS * 2) * 12 <= (size_t)V.lds_bytes && TS * 2 <= P && (V.ls_hbm < 2 || TS * 2 <= V.ls_hbm)) TS <<= 1; /* (ls_hbm >= 2: a test's cap on the tile) */
+    double QP_LDS_AS *tk = QP_LDS_ARG(double, lds);
+    int QP_LDS_AS *ti = QP_LDS_ARG(int, lds + (size_t)TS * 8);
+    auto tile_pass = [&](const int kfrom, const int kto) QP_ALWAYS_INLINE {
+      for (int t0 = 0; t0 < P; t0 += TS) {
+        for (int e = tid; e < TS; e += QP_T) { tk[e] = keys[t0 + e]; ti[e] = idx[t0 + e]; }
+        __syncthreads();
+        for (int k = kfrom; k <= kto; k <<= 1) {
+          const int j0 = ((k >> 1) < (TS >> 1)) ? (k >> 1) : (TS >> 1);
+          for (int j = j0, lj = 31 - __builtin_clz(j0); j > 0; j >>= 1, lj--) {
+            for (int e = tid; e < (TS >> 1); e += QP_T) {
+              const int i = ((e >> lj) << (lj + 1)) + (e & (j - 1)), p = i + j;
+              const bool up = (((t0 + i) & k) == 0);
+              const double ki = tk[i], kp = tk[p];
+              const int ii = ti[i], ip = ti[p];
+              if (ls_greater(ki, ii, kp, ip) == up) { tk[i] = kp; tk[p] = ki; ti[i] = ip; ti[p] = ii; }
+            }
+            if (j > 32) __syncthreads(); else QP_WAVE_SYNC();
+          }
+          __syncthreads();
+        }
+        for (int e = tid; e < TS; e += QP_T) { keys[t0 + e] = tk[e]; idx[t0 + e] = ti[e]; }
+        __syncthreads();
+      }
+    };
+    tile_pass(2, TS);
+    for (int k = TS << 1; k <= P; k <<= 1) {
+      for (int j = k >> 1, lj = 31 - __builtin_clz(k >> 1); j >= TS; j >>= 1, lj--) {
+        for (int e = tid; e < (P >> 1); e += QP_T) {
+          const int i = ((e >> lj) << (lj + 1)) + (e & (j - 1)), p = i + j;
+          const bool up = ((i & k) == 0);
+          const double ki = keys[i], kp = keys[p];
+          const int ii = idx[i], ip = idx[p];
+          if (ls_greater(ki, ii, kp, ip) == up) { keys[i] = kp; keys[p] = ki; idx[i] = ip; idx[p] = ii; }
+        }
+        __syncthreads();
+      }
+      tile_pass(k, k);
+    }
+  } else
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1, lj = 31 - __builtin_clz(k >> 1); j > 0; j >>= 1, lj--) { /* j = 1 << lj: shifts, no integer division */
       for (int e = tid; e < (P >> 1); e += QP_T) {
@@ -578,8 +623,8 @@ QPPH double dev_linesearch(const qpg_view &V, const QpArrays &a, IterShared &I, 
     if (dl > 0) { ra = ra + dl * dl; rb = rb - dl * al; } else { ra = ra - dl * dl; rb = rb + dl * al; }
   }
   };
-  if (in_lds) sort_and_scan((double *)lds, (int *)(lds + (size_t)P2 * 8));
-  else sort_and_scan(a.ls_key() + 0, a.ls_idx() + 0); /* keys are compacted in place */
+  if (in_lds) sort_and_scan((double *)lds, (int *)(lds + (size_t)P2 * 8), std::false_type());
+  else sort_and_scan(a.ls_key() + 0, a.ls_idx() + 0, std::true_type()); /* keys are compacted in place */
   const int pos = block_imin(I.S, mypos);
   __syncthreads();
   if (pos == 0x7fffffff) { if (tid == 0) I.S.bc[0] = -(b0 + tb) / (a0 + ta); }

@@ -79,24 +79,34 @@ QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, boo
       const int e0 = on ? S.Lp[j] : 0, e1 = on ? S.Lp[j + 1] : 0;
       /* ---- A' Sigma A, column j: active rows t ascending, lanes over the entries of row t (distinct columns i: no conflicts) ---- */
       if (with_AtSA) {
+        /* what a row costs is its chain of dependent round trips (row index -> active flag, value, row pointers -> entries), so the
+         * group's lanes fetch that chain for spg rows of the column AT ONCE and the rows are then taken in order from the lanes */
         const int p0 = on ? Ap[jo] : 0, p1 = on ? Ap[jo + 1] : 0;
         const int np = wave_imax(p1 - p0);
-        for (int pp = 0; pp < np; pp++) {
-          const int p = p0 + pp;
-          int t = 0;
-          bool act = p < p1;
-          if (act) { t = Ai[p]; act = active[t] != 0; }
-          const double vj = act ? Atss[Ainv[p]] : 0.0;
-          const int q0 = act ? Atp[t] : 0, q1 = act ? Atp[t + 1] : 0;
-          const int nq = wave_imax(q1 - q0);
-          for (int qq = gl; qq < nq; qq += spg) {
-            const int q = q0 + qq;
-            if (q < q1) {
-              const int i = S.AtiP[q];
-              if (i >= j) w[i] += Atss[q] * vj;
-            }
+        for (int pb = 0; pb < np; pb += spg) {
+          const int pm = p0 + pb + gl;
+          int tq0 = 0, tq1 = 0;
+          double tv = 0.0;
+          if (pm < p1) {
+            const int t = Ai[pm];
+            if (active[t]) { tv = Atss[Ainv[pm]]; tq0 = Atp[t]; tq1 = Atp[t + 1]; }
           }
-          QP_WAVE_SYNC();
+          const int cnt = (np - pb < spg) ? (np - pb) : spg;
+          for (int sidx = 0; sidx < cnt; sidx++) {
+            const int src = (lane & ~(spg - 1)) + sidx;
+            const double vj = __shfl(tv, src);
+            const int q0 = __shfl(tq0, src), q1 = __shfl(tq1, src);
+            const int nq = wave_imax(q1 - q0);
+            if (nq == 0) continue; /* (the same for every lane of the wavefront: no row of this round is active) */
+            for (int qq = gl; qq < nq; qq += spg) {
+              const int q = q0 + qq;
+              if (q < q1) {
+                const int i = S.AtiP[q];
+                if (i >= j) w[i] += Atss[q] * vj;
+              }
+            }
+            QP_WAVE_SYNC();
+          }
         }
       }
       /* ---- + Q(:, j) (both triangles are stored: the lower one of the permuted matrix is picked here), + 1 / gamma ---- */
@@ -110,23 +120,30 @@ QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, boo
       QP_WAVE_SYNC();
       if (on && proximal && gl == 0) w[j] += 1.0 / gamma;
       QP_WAVE_SYNC();
-      /* ---- left-looking updates: every column k < j with l_jk != 0, ascending ---- */
+      /* ---- left-looking updates: every column k < j with l_jk != 0, ascending.  Column k was finished in an earlier level, so l_jk, d_k
+       * and the column's extent can be fetched for spg of them at once (one lane each), then applied in order ---- */
       {
         const int r0 = on ? S.Rp[j] : 0, r1 = on ? S.Rp[j + 1] : 0;
         const int nr = wave_imax(r1 - r0);
-        for (int rr = 0; rr < nr; rr++) {
-          const int r = r0 + rr;
-          const bool has = r < r1;
-          const int k = has ? S.Rk[r] : 0, pos = has ? S.Rpos[r] : 0;
-          const double ljk = has ? S.Lx[pos] : 0.0;
-          const double mk = has ? ljk * S.Dg[k] : 0.0;
-          if (has && gl == 0) w[j] = QP_FMA(-ljk, mk, w[j]);
-          const int k1 = has ? S.Lp[k + 1] : 0;
-          for (int e = pos + 1 + gl; e < k1; e += spg) { /* rows below j of column k: they all belong to column j's pattern */
-            const int i = S.Li[e];
-            w[i] = QP_FMA(-S.Lx[e], mk, w[i]);
+        for (int rb = 0; rb < nr; rb += spg) {
+          const int rm = r0 + rb + gl;
+          int tpos = 0, tk1 = 0;
+          double tl = 0.0, td = 0.0;
+          if (rm < r1) { const int k = S.Rk[rm]; tpos = S.Rpos[rm]; tl = S.Lx[tpos]; td = S.Dg[k]; tk1 = S.Lp[k + 1]; }
+          const int cnt = (nr - rb < spg) ? (nr - rb) : spg;
+          for (int sidx = 0; sidx < cnt; sidx++) {
+            const int src = (lane & ~(spg - 1)) + sidx;
+            const double ljk = __shfl(tl, src);
+            const double mk = ljk * __shfl(td, src);
+            const int pos = __shfl(tpos, src), k1 = __shfl(tk1, src);
+            const bool has = r0 + rb + sidx < r1;
+            if (has && gl == 0) w[j] = QP_FMA(-ljk, mk, w[j]);
+            for (int e = pos + 1 + gl; e < k1; e += spg) { /* rows below j of column k: they all belong to column j's pattern (k1 = 0 where the group has no such column) */
+              const int i = S.Li[e];
+              w[i] = QP_FMA(-S.Lx[e], mk, w[i]);
+            }
+            QP_WAVE_SYNC();
           }
-          QP_WAVE_SYNC();
         }
       }
       /* ---- pivot and column; the work vector goes back to zero ---- */

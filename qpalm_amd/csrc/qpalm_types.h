@@ -130,6 +130,7 @@ typedef struct {
   int32_t *sp_perm;         /* [B][n] the factor is that of P H P': perm[new] = old (identity: natural ordering) */
   int32_t *sp_AtiP, *sp_QfiP, *sp_first; /* [B][nnzA] Ati, [B][nnzQf] Qfi in the factor's numbering; [B][m] first (smallest) such column of every row of A */
   double *sp_tmp;           /* [nslots][n] the permuted right-hand side of a solve */
+  int32_t ls_hbm;           /* tests: >= 1 = the line search keeps its sort buffer in HBM (the LDS-tiled sort) whatever m; >= 2: tiles of at most that many entries */
   int32_t sp_gpw;           /* columns a wavefront factorises at a time (1, 2 or 4 groups of 64 / sp_gpw lanes): sp_wv holds wavefronts x sp_gpw work vectors per slot */
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */

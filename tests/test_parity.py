@@ -767,3 +767,23 @@ def test_large_factor_path(ctx):
     st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     bt = _compare_solve(ctx, [p], st)
     assert int(bt.stats(0).n_rank1) > 0 and int(bt.stats(0).n_sweeps) > 0
+
+
+def test_linesearch_sort_buffer_in_hbm_with_lds_tiles(ctx):
+    """more breakpoints than the LDS holds (m > 3200 or so: configs 2' and 5, every large sparse QP) are sorted in HBM, a tile of them at a
+    time through all the short-distance steps of the bitonic network in LDS.  Same network: forced here on small QPs (context option
+    linesearch_hbm), the iterates must be BIT-identical to the in-LDS sort's, and equal to the oracle's."""
+    n, m = sizes(ctx, (40, 90), (300, 700))
+    probs = [random_qp(n, m, seed=8100 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(2)]
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    out = {}
+    try:
+        for hbm in (0, 1, 32):       # 32: tiles of 32 entries -- several tiles and the long-distance steps in HBM between them
+            ctx.set_option("linesearch_hbm", hbm)
+            bt = _compare_solve(ctx, probs, st)
+            out[hbm] = bt.solution()
+            bt.close()
+    finally:
+        ctx.set_option("linesearch_hbm", 0)
+    for hbm in (1, 32):
+        assert np.array_equal(out[0][0], out[hbm][0]) and np.array_equal(out[0][1], out[hbm][1]), hbm
