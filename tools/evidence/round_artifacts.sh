@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/$R/final
 mkdir -p $OUT
 cd $REPO
-timeout 1800 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
+timeout 1800 python -m pytest tests -q -m gpu --timeout 400 > $OUT/pytest_gpu.log 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel trace (own run) and the PMC passes (separate runs, counters only), all of the default bench command
@@ -35,12 +35,12 @@ timeout 300 python tools/evidence/sweep_probe.py cur --reps 4 --ranks 16 8 > $OU
 timeout 300 python tools/evidence/setup_timing.py 8192 > $OUT/setup_timing.txt 2>&1
 timeout 600 python tools/evidence/coop_timing.py 512 1000 2500 5000 > $OUT/coop_timing.txt 2>> $OUT/bench_default.err
 # config 5 as written (n = 5000 nonconvex): wall time and the coop profile of one solve, every round
-QPALM_COOP_PROFILE=1 timeout 900 python -m pytest tests/test_coop.py -q -m gpu -k config5 -s > $OUT/config5.txt 2>&1
+QPALM_COOP_PROFILE=1 timeout 600 python -m pytest tests/test_coop.py -q -m gpu -k config5 -s --timeout 300 > $OUT/config5.txt 2>&1
 # batch sizes between "one QP" and "the chip is full" (missing #2)
 mkdir -p $REPO/gpurun_out/$R/batch
 for b in 16 64 128 256; do timeout 300 python bench.py --batch $b --steps 3 --warmup 1 --no-cpu --no-mpc > $REPO/gpurun_out/$R/batch/bench_b$b.json 2>> $OUT/bench_default.err; done
 # the sparse factor at size
-timeout 1200 python -m pytest tests/test_sparse_factor.py -q -m gpu -s > $OUT/sparse_factor_at_size.txt 2>&1
+timeout 600 python -m pytest tests/test_sparse_factor.py -q -m gpu -s --timeout 150 > $OUT/sparse_factor_at_size.txt 2>&1
 timeout 300 tools/evidence/sload_coherence_test > $OUT/sload_coherence.txt 2>&1
 timeout 200 tools/evidence/host_alloc_probe > $OUT/host_alloc_probe.txt 2>&1
 ls -la $OUT
