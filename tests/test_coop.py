@@ -71,7 +71,7 @@ def test_coop_update_sweep_in_one_launch_equals_the_chain_of_launches(ctx):
     diagonal blocks hand their tables down through a counter; = 1: one launch per 32-column block.  Same arithmetic per entry: the two
     must agree BIT FOR BIT (x, y and the counts), and with the one-workgroup path to rounding.  Sizes: three / eight row chunks, the last
     one ragged; more than 16 ranks in some iterations (two sweeps)."""
-    n, m = sizes(ctx, (300, 420), (1000, 2000))
+    n, m = sizes(ctx, (260, 300), (1000, 2000))
     p = random_qp(n, m, seed=4242, density_A=0.01 if n >= 400 else 4.0 / n, density_M=0.005 if n >= 400 else 2.0 / n)
     st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     res = {}

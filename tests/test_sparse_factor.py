@@ -136,6 +136,40 @@ def test_sparse_factor_batch_of_different_patterns(ctx):
         ctx.set_option("sparse_ordering", -1)
 
 
+def test_nested_dissection_with_a_long_row_and_hubs(ctx):
+    """the ordering's corner cases: a row of A with more entries than the ordering graph spells out as a clique (> 64: it enters as a chain of
+    its columns; the symbolic analysis that follows still sees the clique), and a band plus vertices of very high degree (set aside,
+    ordered last) -- a valid permutation either way, and the solve equal to the oracle's under it"""
+    rng = np.random.default_rng(5)
+    p = sparse_qp(150, "banded", seed=8)
+    A = sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n)).tolil()
+    cols = rng.choice(p.n, size=70, replace=False)
+    A[3, cols] = 0.1 * rng.standard_normal(70)
+    A = sp.csc_matrix(A); A.sort_indices()
+    p1 = type(p)(p.n, p.m, p.Qp, p.Qi, p.Qx, A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64), p.q, p.bmin, p.bmax)
+    p2 = sparse_qp(120, "arrow", seed=9)
+    ctx.set_option("sparse_factor", 1)
+    ctx.set_option("sparse_ordering", 1)
+    try:
+        for q in (p1, p2):
+            bt = QpalmBatch(ctx, [q], ctx.default_settings(**ST))
+            perm, levels = bt.sparse_perm(0)
+            assert np.array_equal(np.sort(perm), np.arange(q.n))
+            if q is p1 and ctx.kind == "emu":     # (the 70-clique's chain of levels takes the emulator a minute and a half: ordering + analysis here, the solve on the hardware)
+                bt.close()
+                continue
+            bt.solve()
+            x, y = bt.solution()
+            o = oracle_sparse(q, perm, **ST)
+            assert int(bt.info(0).status_val) == o.status_val == 1 and int(bt.info(0).iter) == int(o.info.iter)
+            assert rel(x[0], o.x) <= 1e-9 and rel(y[0], o.y) <= 1e-9
+            bt.close()
+        assert perm[-1] == p2.n - 1          # the arrow's shaft (the dense last row / column of Q) goes last
+    finally:
+        ctx.set_option("sparse_factor", -1)
+        ctx.set_option("sparse_ordering", -1)
+
+
 @pytest.mark.parametrize("kind,n", [("banded", 3000), ("arrow", 2000), ("blocks", 1600)])
 def test_nested_dissection_makes_chains_into_trees(ctx, kind, n):
     """the symbolic side alone (no solve): a band's elimination tree under the natural ordering is a chain of n columns; dissected, its
