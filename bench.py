@@ -59,7 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="random-1000", choices=("random-1000", "mpc-160"))
+    ap.add_argument("--workload", default="random-1000", choices=("random-1000", "mpc-160", "sparse-banded-2000", "sparse-blocks-2000"),
+                    help="random-1000: the headline (BASELINE.json configs[1]); mpc-160: config 3; sparse-*: a batch of sparse QPs with n = 2000 on the "
+                         "sparse factor (SURVEY section 8 row h; default batch 2048): QP/s and the phase split, no byte model")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("QPALM_BENCH_BATCH", "8192")),
                     help="QPs per GPU (512 resident factor slots = workgroups; the rest queue up behind them)")
     ap.add_argument("--n", type=int, default=0, help="random workload: number of variables (default 1000)")
@@ -185,7 +187,7 @@ def write_problem_file(path, problems, settings_kw):
                 f.write(np.ascontiguousarray(arr, dtype=dt).tobytes())
 
 
-def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
+def cpu_baseline(problems, settings_kw, workload, budget_s=20.0, sparse=False):
     """Oracle ("port") on the host cores through a C pthread harness (oracle/cpu_bench.c: one workspace per thread, no
     Python in the timed loop); bounded sample.  Reported next to the GPU figure, not a target."""
     cores = max(1, min(os.cpu_count() or 1, 256))
@@ -195,7 +197,7 @@ def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
     try:
         def run(sample, threads, passes=1):
             write_problem_file(pfile, sample, settings_kw)
-            r = subprocess.run([exe, pfile, str(threads), str(passes)], capture_output=True, text=True)
+            r = subprocess.run([exe, pfile, str(threads), str(passes), "1" if sparse else "0"], capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("cpu_bench failed (rc %d): %s %s" % (r.returncode, r.stdout[-300:], r.stderr[-300:]))
             return json.loads(r.stdout.strip().splitlines()[-1])
@@ -229,9 +231,9 @@ def cpu_baseline(problems, settings_kw, workload, budget_s=20.0):
             "single_qp_alone_s": t_probe, "iter_mean": res["iter_mean"], "wall_s": res["wall_s"], "threads_tried_qps": calib,
             "cholmod_probe": probe_lib,
             "sample": "%d of the batch's %s QPs x %d pass(es), setup + solve timed as info.run_time does (eps 1e-6), %d pthreads (the fastest of the thread counts in threads_tried_qps) pulling QPs from a "
-                      "shared counter (oracle/cpu_bench.c, no Python in the loop), oracle/qpalm_oracle.c (dense LDL', scalar rank-1 sweeps) "
+                      "shared counter (oracle/cpu_bench.c, no Python in the loop), oracle/qpalm_oracle.c (%s) "
                       "built -O3 -march=native; one QP alone on one core: %.4f s; %s"
-                      % (nsample, workload, passes, cores, t_probe,
+                      % (nsample, workload, passes, cores, "sparse-storage L D L', natural ordering, path updates" if sparse else "dense LDL', scalar rank-1 sweeps", t_probe,
                          "a system CHOLMOD is present (probe in cholmod_probe) but this figure is the restatement" if have else
                          "no system CHOLMOD on the box (probe in cholmod_probe), so this is the restatement, not CHOLMOD")}
 
@@ -330,6 +332,71 @@ def mpc160_line(ctx, B, kkt, steps, warmup=1):
     return out
 
 
+def sparse_workload(args, ctx, rank, world, dist, torch):
+    """`--workload sparse-banded-2000 | sparse-blocks-2000`: B (default 2048) sparse QPs with n = 2000 per GPU on the sparse L D L'
+    (qpalm_sparse.h: one workgroup per QP, nested-dissection ordering where the natural elimination tree is a chain).  The kernel is
+    bound by chains of dependent round trips, not by bytes: the line carries the phase split instead of a roofline."""
+    import numpy as np
+    from qpalm_amd.problems import sparse_qp
+    from qpalm_amd.solver import QpalmBatch
+    kind = args.workload.split("-")[1]
+    n = args.n or 2000
+    B = args.batch if args.batch != 8192 else 2048
+    ctx.set_option("sparse_factor", 1)
+    settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    distinct = [sparse_qp(n, kind, seed=700 + 64 * rank + k) for k in range(64)]
+    probs = [distinct[k % 64] for k in range(B)]
+    bt = QpalmBatch(ctx, probs, ctx.default_settings(**settings_kw))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        bt.warm_start(None, None)
+        bt.solve()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    infos, stats = bt.infos(), bt.stats_all()
+    xs, ys = bt.solution()
+    ok = all(int(i.status_val) == 1 for i in infos) and kkt_spot_check(probs, xs, ys, sorted({0, B // 3, B // 2, B - 1})) <= 1e-4
+    mean = lambda f: float(np.mean([f(s) for s in stats]))
+    perm, levels = bt.sparse_perm(0)
+    nnzL, nbytes = bt.sparse_info(0)
+    if rank != 0:
+        return 0 if ok else 1
+    out = {"metric": "QP/s", "value": world * B * args.steps / elapsed, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%s: batch of %d sparse QPs per GPU (%s pattern, n=%d m=%d), sparse L D L' with %d levels (ordering: %s), nnz(L)=%d, eps 1e-6, cold start"
+                                  % (args.workload, B, kind, probs[0].n, probs[0].m, levels, "natural" if np.array_equal(perm, np.arange(len(perm))) else "nested dissection", nnzL),
+                      "batch_per_gpu": B, "n": probs[0].n, "m": probs[0].m, "kernel": "k_solve<sparse>", "parallelism": "batch-shard x%d" % world, "device_block_MB": nbytes / 2 ** 20},
+           "roofline": None,
+           "solve_stats": {"all_solved": bool(ok), "iter_mean": float(np.mean([int(i.iter) for i in infos])),
+                           "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_rank1", "n_solve")},
+                           "ms_per_qp_in_kernel": {"total": mean(lambda s: s.ms_total), "factor": mean(lambda s: s.ms_factor), "update": mean(lambda s: s.ms_update), "solve": mean(lambda s: s.ms_solve),
+                                                   "linesearch": mean(lambda s: s.ms_linesearch), "residuals": mean(lambda s: s.ms_dbg[12])},
+                           "note": "latency-bound (chains of dependent round trips per column and per level), no byte model: roofline is null for this workload"}}
+    if not args.no_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(distinct, settings_kw, args.workload, budget_s=15.0, sparse=True)
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)[:300]}
+    bt.close()
+    print(json.dumps(out))
+    return 0 if ok else 1
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def worker(args):
     import numpy as np
@@ -376,6 +443,8 @@ def worker(args):
     if not args.narrow_rows:
         ctx.set_option("narrow_rows", 0)
     B = args.batch
+    if args.workload.startswith("sparse-"):
+        return sparse_workload(args, ctx, rank, world, dist, torch)
     settings_kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
     if args.kkt:
         settings_kw["factorization_method"] = 0

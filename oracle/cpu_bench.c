@@ -6,7 +6,8 @@
  * (/root/reference/src/qpalm.c:493-495,721-723), here clock_gettime(CLOCK_MONOTONIC) around oq_setup + oq_solve;
  * oq_cleanup is outside the per-QP figure but inside the wall time the throughput is computed from.
  *
- *   cpu_bench <problems.bin> <threads> [passes]
+ *   cpu_bench <problems.bin> <threads> [passes] [sparse]      (sparse = 1: the oracle's sparse-storage mode, natural ordering: what the
+ *                                                              reference hands to CHOLMOD for a sparse Schur complement)
  *
  * File layout (little endian, written by bench.py): int64 magic 0x5150424e, int64 count, oq_settings, then per QP
  *   int64 n, m, nnzQ, nnzA; Qp[n+1] Qi[nnzQ] (int64) Qx[nnzQ] (double); Ap[n+1] Ai[nnzA] Ax[nnzA]; q[n]; c; bmin[m]; bmax[m].
@@ -34,6 +35,7 @@ static problem *g_prob;
 static oq_int g_count, g_total;
 static oq_settings g_settings;
 static volatile oq_int g_next;
+static int g_sparse;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static double g_sum_run, g_sum_solve;
 static oq_int g_solved, g_iters;
@@ -58,6 +60,7 @@ static void *worker(void *arg) {
     oq_workspace *w = oq_setup(p->n, p->m, p->Qp, p->Qi, p->Qx, p->Ap, p->Ai, p->Ax, p->q, p->c, p->bmin, p->bmax, &g_settings);
     const double t1 = now_s();
     if (!w) continue;
+    if (g_sparse) oq_set_scalar(w, "sparse_mode", 1);
     oq_solve(w);
     const double t2 = now_s();
     const oq_info *info = oq_get_info(w);
@@ -79,6 +82,7 @@ int main(int argc, char **argv) {
   if (argc < 3) { fprintf(stderr, "usage: cpu_bench problems.bin threads [passes]\n"); return 2; }
   const int threads = atoi(argv[2]) > 0 ? atoi(argv[2]) : 1;
   const int passes = (argc > 3 && atoi(argv[3]) > 0) ? atoi(argv[3]) : 1;
+  g_sparse = (argc > 4 && atoi(argv[4]) > 0) ? 1 : 0;
   /* keep the workspaces of successive QPs on the heap of the thread's arena: with the default thresholds every setup / cleanup
    * pair maps and unmaps its multi-megabyte arrays, and the threads then queue on the process's address-space lock */
   mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);

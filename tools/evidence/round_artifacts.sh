@@ -41,6 +41,9 @@ mkdir -p $REPO/gpurun_out/$R/batch
 for b in 16 64 128 256; do timeout 300 python bench.py --batch $b --steps 3 --warmup 1 --no-cpu --no-mpc > $REPO/gpurun_out/$R/batch/bench_b$b.json 2>> $OUT/bench_default.err; done
 # the sparse factor at size
 timeout 600 python -m pytest tests/test_sparse_factor.py -q -m gpu -s --timeout 150 > $OUT/sparse_factor_at_size.txt 2>&1
+# batches of sparse QPs on the sparse factor (SURVEY section 8 row h), with the oracle's sparse-storage mode on the host cores beside them
+timeout 400 python bench.py --workload sparse-banded-2000 > $OUT/bench_sparse_banded_2000.json 2>> $OUT/bench_default.err
+timeout 400 python bench.py --workload sparse-blocks-2000 > $OUT/bench_sparse_blocks_2000.json 2>> $OUT/bench_default.err
 timeout 300 tools/evidence/sload_coherence_test > $OUT/sload_coherence.txt 2>&1
 timeout 200 tools/evidence/host_alloc_probe > $OUT/host_alloc_probe.txt 2>&1
 ls -la $OUT
