@@ -34,11 +34,46 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def lib_sha256(path=None):
-    """hash of the built HIP library that is loaded (a stale .so must not have another build's counters quoted for it)"""
+    """hash of the DEVICE CODE of the built HIP library that is loaded (a stale .so must not have another build's counters quoted for
+    it): the .text and .rodata sections of the gfx950 code object inside the shared object's `.hip_fatbin` section.  Not the whole
+    file -- hipcc gives every compilation a random `__hip_cuid_*` symbol, so two builds of the same sources differ in a few hundred
+    bytes of the host AND device symbol tables while the machine code is identical (a rebuild on another machine -- the driver's
+    build() -- must still find its counters)."""
     import hashlib
+    import struct
     from qpalm_amd import capi
     with open(path or capi.LIB_PATH, "rb") as fh:
-        return hashlib.sha256(fh.read()).hexdigest()
+        blob = fh.read()
+
+    def sections(elf):   # ELF64 little endian: {name: bytes}
+        if elf[:4] != b"\x7fELF" or elf[4] != 2:
+            raise ValueError("not ELF64")
+        shoff, = struct.unpack_from("<Q", elf, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+        hdr = [struct.unpack_from("<IIQQQQ", elf, shoff + k * shentsize) for k in range(shnum)]
+        names = elf[hdr[shstrndx][4]:hdr[shstrndx][4] + hdr[shstrndx][5]]
+        return {names[h[0]:names.index(b"\0", h[0])]: elf[h[4]:h[4] + h[5]] for h in hdr if h[1] != 8}   # (8 = SHT_NOBITS)
+    try:
+        fat = sections(blob)[b".hip_fatbin"]
+        if fat[:24] != b"__CLANG_OFFLOAD_BUNDLE__":
+            raise ValueError("unexpected bundle format")
+        count, = struct.unpack_from("<Q", fat, 24)
+        pos, h, found = 32, hashlib.sha256(), False
+        for _ in range(count):
+            off, size, tlen = struct.unpack_from("<QQQ", fat, pos)
+            triple = fat[pos + 24:pos + 24 + tlen]
+            pos += 24 + tlen
+            if b"gfx950" in triple and size:
+                dev = sections(fat[off:off + size])
+                for name in (b".text", b".rodata"):
+                    h.update(name)
+                    h.update(dev.get(name, b""))
+                found = True
+        if not found:
+            raise ValueError("no gfx950 code object")
+        return h.hexdigest()
+    except Exception:   # noqa: BLE001 -- an unexpected layout: the whole file (never matches another build, which is the safe side)
+        return hashlib.sha256(blob).hexdigest()
 
 
 def source_sha256():
