@@ -88,7 +88,8 @@ def load(path=None):
     L.qpg_batch_iterate.argtypes = [C.c_void_p, c_int]
     L.qpg_batch_num_unfinished.argtypes = [C.c_void_p, pi]
     L.qpg_batch_launch_shape.argtypes = [C.c_void_p, pi, pi, pi]
-    L.qpg_batch_sparse_info.argtypes = [C.c_void_p, c_int, pi, pi]
+    if hasattr(L, "qpg_batch_sparse_info"):
+        L.qpg_batch_sparse_info.argtypes = [C.c_void_p, c_int, pi, pi]
     if hasattr(L, "qpg_batch_sparse_perm"):   # (absent from older builds of the library that tools/evidence/gpu_ab.sh compares with)
         L.qpg_batch_sparse_perm.argtypes = [C.c_void_p, c_int, pi, pi]
     L.qpg_batch_last_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]

@@ -14,3 +14,8 @@ timeout 600 python $F 642 60 hip 257 600 sparse=1 ordering=1 > $OUT/sparse_disse
 timeout 600 python $F 651 200 hip 2 70 linesearch_hbm=32 > $OUT/tiled_sort_651.log 2>&1
 timeout 600 python $F 661 200 hip 2 70 nonconvex=1 q_shift=1.0 > $OUT/nonconvex_661.log 2>&1
 tail -q -n 1 $OUT/*.log
+# coop mode forced on single QPs of 130..600 variables under the reference's refactorise-or-update rule: the one-launch update sweep
+# (two to five row chunks, ragged last blocks, downdates, first nonzero anywhere) on random patterns
+timeout 900 python $F 681 150 hip 130 600 coop=1 coop_rank_threshold=-1 factorization_method=1 > $OUT/coop_sweep_681.log 2>&1
+timeout 900 python $F 682 60 hip 130 600 coop=1 coop_rank_threshold=-1 factorization_method=1 nonconvex=1 q_shift=1.0 > $OUT/coop_sweep_nonconvex_682.log 2>&1
+tail -q -n 1 $OUT/coop_sweep*.log
