@@ -1089,6 +1089,22 @@ template <int N> QPD double qp_row_shr(double v) {
   return __hiloint2double(hi, lo);
 }
 #endif
+/* The pivot of a column after rank r of a sweep is d_0 + p_0 + ... + p_r.  The sweeps add the p's as a prefix TREE over the 16 lanes of a DPP
+ * row (four steps); this is the same sum taken the way the reference takes it, rank after rank: d_r = d_{r-1} + p_r, fifteen dependent
+ * steps.  Same value in exact arithmetic -- but when downdates take a pivot through (almost) zero on an INDEFINITE factor, the tree's
+ * partial sums of p's alone are large next to the running pivot, their rounding error is relative to them and not to it, and the factor
+ * never recovers from it the way the sequential form does (round 5, fuzz case 682 / 1: D to 7e-7 instead of 2e-10 five iterations after
+ * a pivot of 3.6e-5; the solve then needs 13 339 instead of 2459 iterations).  Used for nonconvex QPs (QpShared::seq_ranks). */
+template <int KG> QPD double qp_rank_prefix_seq(const double p, const int ln) {
+  double incl = p;
+#pragma unroll
+  for (int sq = 1; sq < KG; sq++) {
+    const double up = qp_row_shr<1>(incl);
+    if ((ln & 15) == sq) incl = up + p;
+  }
+  return incl;
+}
+
 
 /* lane R of every row of 16 lanes to all lanes of that row (DPP row_newbcast:R): no LDS, no SGPR */
 #ifdef QPALM_EMU
@@ -1200,6 +1216,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   /* pre_jmin >= 0: ONE rank whose dense vector the caller has already written to Wst[0 .. n) (first nonzero at
    * pre_jmin), sign +1 if n_up == 1 else -1: the trailing update of a KKT row addition / deletion */
   const int pre_jmin = QP_UNIFORM(pre_jmin_);
+  const bool seq = QP_UNIFORM(S_->seq_ranks) != 0; /* (set by dev_updown behind a barrier) */
   /* fs != NULL: the LAST sweep also does the forward substitution L y = b of the solve that follows (same ascending
    * column order: an entry of L is used for the substitution right after its last rank has been applied, so the panel
    * is not streamed a second time for it).  In: b, out: y.  The sweep then starts at column 0. */
@@ -1597,10 +1614,14 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             if (QP_PANEL_TIMING == 2 && g == 0) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
             const double p = sg[g] * wv * wv * ialpha[g];
             double incl = p;
-            if (KG > 1) incl += qp_row_shr<1>(incl);
-            if (KG > 2) incl += qp_row_shr<2>(incl);
-            if (KG > 4) incl += qp_row_shr<4>(incl);
-            if (KG > 8) incl += qp_row_shr<8>(incl);
+            if (seq) { /* d_r = d_{r-1} + p_r, rank after rank: see qp_rank_prefix_seq */
+              incl = qp_rank_prefix_seq<KG>(p, ln);
+            } else {
+              if (KG > 1) incl += qp_row_shr<1>(incl);
+              if (KG > 2) incl += qp_row_shr<2>(incl);
+              if (KG > 4) incl += qp_row_shr<4>(incl);
+              if (KG > 8) incl += qp_row_shr<8>(incl);
+            }
             const double excl = qp_row_shr<1>(incl);
             const double dnew = d0 + incl, dprev = d0 + excl;
             const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
@@ -1774,7 +1795,7 @@ struct UpdownBigLds {
 #endif
 template <int K>
 QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const int jb, const int kk, const double sg,
-                          double (&wrow)[K], double &dreg, double &alpha, double &ialpha) {
+                          double (&wrow)[K], double &dreg, double &alpha, double &ialpha, const bool seq = false) {
   static_assert(K == 16 || !QP_PANEL_DPP, "the DPP form needs one rank per lane of a 16-lane row");
   double lnext = (lane > 0 && lane < jb) ? U.Ld[lane][0] : 0.0;
 #pragma unroll 1
@@ -1792,10 +1813,14 @@ QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const in
     const double d0 = qp_readlane(dreg, c1);
     const double p = sg * wv * wv * ialpha;
     double incl = p;
-    if (K > 1) incl += qp_row_shr<1>(incl);
-    if (K > 2) incl += qp_row_shr<2>(incl);
-    if (K > 4) incl += qp_row_shr<4>(incl);
-    if (K > 8) incl += qp_row_shr<8>(incl);
+    if (seq) {
+      incl = qp_rank_prefix_seq<K>(p, ln);
+    } else {
+      if (K > 1) incl += qp_row_shr<1>(incl);
+      if (K > 2) incl += qp_row_shr<2>(incl);
+      if (K > 4) incl += qp_row_shr<4>(incl);
+      if (K > 8) incl += qp_row_shr<8>(incl);
+    }
     const double excl = qp_row_shr<1>(incl);
     const double dnew = d0 + incl, dprev = d0 + excl;
     const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
@@ -1880,7 +1905,7 @@ QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb && r < kk) ? Wst[(size_t)r * n + J + lane] : 0.0;
         double dreg = (lane < jb) ? U.dd[lane] : 1.0;
-        updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha);
+        updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, QP_UNIFORM(S.seq_ranks) != 0);
         if (lane < jb) Dg[J + lane] = dreg;
 #pragma unroll 1
         for (int c = 0; c < jb; c++)
@@ -1956,7 +1981,7 @@ QPD void co_updown_init(const int *Atp, const int *Ati, const double *Atss, cons
 /* block column J (J >= n: only the pending stage is written back) */
 template <int K>
 QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, double *Wst, double *hst, const int J, const int r0, const int kk,
-                         const int n_up, char *lds, const int wg, const int nwg) {
+                         const int n_up, char *lds, const int wg, const int nwg, const bool seq) {
   typedef UpdownBigLds<K> LdsT;
   LdsT QP_LDS_AS &U = *QP_LDS_ARG(LdsT, lds);
   const int NB = QP_UNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1991,7 +2016,7 @@ QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, doubl
     double alpha = (rl < K) ? hst[par * 2 * K + rl] : 1.0, ialpha = (rl < K) ? hst[par * 2 * K + K + rl] : 1.0;
     const int grank = r0 + rl;
     const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
-    updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha);
+    updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, seq);
     if (wg == 0) {
       if (lane < K) { hst[(1 - par) * 2 * K + lane] = alpha; hst[(1 - par) * 2 * K + K + lane] = ialpha; }
       if (lane < jb) hst[CO_UD_D + lane] = dreg;
@@ -2073,7 +2098,7 @@ QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, doubl
 #define CO_UD_TAB(K) (QP_UNB * (K) * 2 + 2 * (K)) /* doubles per published table: the block's (-w, -gamma) pairs, then alpha and 1 / alpha per rank */
 template <int K>
 QPD void co_updown_persist(const int n, const int ld, double *L, double *Dg, const double *Wst, const double *hst, double *tab, int *flags,
-                           const int r0, const int kk, const int n_up, char *lds, const int wg, QpShared &S) {
+                           const int r0, const int kk, const int n_up, char *lds, const int wg, QpShared &S, const bool seq) {
   typedef UpdownBigLds<K> LdsT;
   LdsT QP_LDS_AS &U = *QP_LDS_ARG(LdsT, lds);
   double QP_LDS_AS *wd = (double QP_LDS_AS *)(QP_LDS_ARG(char, lds) + ((sizeof(LdsT) + 15) & ~(size_t)15)); /* [NB][K]: running values of a diagonal block's rows */
@@ -2167,7 +2192,7 @@ QPD void co_updown_persist(const int n, const int ld, double *L, double *Dg, con
       }
       const int grank = r0 + rl;
       const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
-      updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha);
+      updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, seq);
       QP_WAVE_SYNC();
       if (lane < jb) Dg[J + lane] = dreg;
 #pragma unroll 1

@@ -176,6 +176,7 @@ struct QpShared {          /* small static LDS block */
   int    hw_simd[QP_NW];   /* SIMD each wavefront of this workgroup sits on */
   int    placement;        /* diagnostic code of the placement (QPGStats.placement) */
   int    panel_wave;       /* the wavefront that runs the serial chains of the update sweep (qp_place_panel_wave) */
+  int    seq_ranks;        /* update sweeps add the ranks' contributions to a pivot one after the other instead of as a prefix tree (dev_updown: nonconvex QPs) */
   int    wave_rank[QP_NW]; /* the sweep's name for each hardware wavefront: 0 = panel wave (owner of the first rows), then the wavefronts that
                               sit on the SIMDs where the CU's panel waves run (they get the rows that retire first), then the rest */
 };
