@@ -186,6 +186,23 @@ def test_round5_certificate_one_iteration_apart_is_explained(ctx):
             assert rounding and "certificate" in why, why
 
 
+def test_round5_indefinite_factor_recovers_from_a_near_zero_pivot(ctx):
+    """Coop-mode campaign at the end of round 5 (profiles/r05/fuzz_final/coop_sweep_nonconvex_682_before_the_fix.log), seed 682 case 1: a
+    nonconvex QP with n = 224 that the oracle and twenty variants of it solve in 2426-2459 iterations took the engine 13 339 (same stationary
+    point; status MAX_ITER at 10 000) -- on one workgroup, in coop mode and on round 4's library alike.  At iteration 200 twenty
+    downdates take a pivot to 3.6e-5; the sweeps' tree-order prefix sum of the ranks' contributions left the factor wrong by 7e-7 from
+    there to the next refactorisation.  Nonconvex QPs now sum rank after rank (qpalm_dense.h: qp_rank_prefix_seq): 2346 iterations."""
+    if ctx.kind == "emu":
+        pytest.skip("2400 iterations at n = 224: minutes in the emulator; runs on the hardware")
+    for it, p, st, warm, meta in cases(682, 2, 130, 600, dict(factorization_method=1, nonconvex=1, q_shift=1.0)):
+        if it != 1:
+            continue
+        r = run_case(ctx, p, st, warm)
+        ok, why, rounding = judge_case(r, p, st, warm, 1e-8, ctx)
+        assert ok, (meta, why, r)
+        assert r["status"] == (1, 1) and r["iter"][0] < 1.2 * r["iter"][1], r
+
+
 @pytest.mark.parametrize("seed,case,n_lo,n_hi", R03_MISMATCHES)
 def test_round3_mismatches_are_rounding_decided(ctx, seed, case, n_lo, n_hi):
     if ctx.kind == "emu" and n_lo > 100:
