@@ -143,6 +143,8 @@ void qpg_ctx_destroy(qpg_ctx *ctx);
  *   "sweep_ranks"           16 (default) or 32 ranks per update sweep (32: the multi-pass sweep, bit-identical factors, slower)
  *   "kkt_compact"           1 = FACTORIZE_KKT factorises the variables + ACTIVE constraints only and spreads the factor out on demand
  *   "place_panel_wave"      0 / 1 / 2: SIMD placement of the sweeps' panel wavefronts (0 = the hardware's own)
+ *   "sequential_rank_sums"  -1 (default) = update sweeps of QPs whose factor can get near-singular (nonconvex; Q without a positive diagonal: LPs) sum
+ *                           a column's pivot rank after rank, the reference's order; 1 = all QPs; 0 = none (prefix tree: faster chain)
  *   "sparse_factor", "sparse_ordering"   the sparse L D L' and its ordering (qpg_batch_sparse_info / qpg_batch_sparse_perm below)
  *   "coop", "coop_workgroups", "coop_updates", "coop_rank_threshold"   one large QP on many workgroups
  * Environment: QPALM_HOST_THREADS = host threads of qpg_batch_set_problems (default: hardware threads, at most 24). */

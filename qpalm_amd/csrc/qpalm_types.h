@@ -68,6 +68,8 @@ typedef struct {
    * iteration is suspended at its linear-algebra site.  pend_stage = 1: the host has to factorise (pend_la = 1 Q + A'SA, 3 Q only,
    * 7 LD_Q of the dual objective; 0 no factorisation) and, for a Newton step (pend_kind == 0, pend_la != 7), to solve for d */
   int32_t pend_stage, pend_la, pend_action, pend_kind, pend_nchange;
+  int32_t seq_hint; /* set by the host at setup: Q has a column without a positive diagonal entry (an LP, a semidefinite Q): the factor's pivots can come down
+                       to 1 / gamma -- its update sweeps sum the ranks' contributions to a pivot one after the other, like those of nonconvex QPs (dev_updown) */
   int32_t kkt_na; /* KKT mode: -1 = the factor slot holds the full (n+m) layout; na >= 0 = the COMPACT factor of the variables + the na constraints listed
                      in kkt_list (the factor is spread out only when a row addition / deletion or a read of the factor needs the full layout) */
   double pend_gam;
@@ -130,6 +132,7 @@ typedef struct {
   int32_t *sp_perm;         /* [B][n] the factor is that of P H P': perm[new] = old (identity: natural ordering) */
   int32_t *sp_AtiP, *sp_QfiP, *sp_first; /* [B][nnzA] Ati, [B][nnzQf] Qfi in the factor's numbering; [B][m] first (smallest) such column of every row of A */
   double *sp_tmp;           /* [nslots][n] the permuted right-hand side of a solve */
+  int32_t seq_mode;         /* context option "sequential_rank_sums": -1 = where the factor can get near-singular (nonconvex QPs, QPs flagged by seq_hint), 1 = always, 0 = never */
   int32_t ls_hbm;           /* tests: >= 1 = the line search keeps its sort buffer in HBM (the LDS-tiled sort) whatever m; >= 2: tiles of at most that many entries */
   int32_t sp_gpw;           /* columns a wavefront factorises at a time (1, 2 or 4 groups of 64 / sp_gpw lanes): sp_wv holds wavefronts x sp_gpw work vectors per slot */
   qpg_scalars *sc; /* [B] */
