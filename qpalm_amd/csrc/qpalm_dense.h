@@ -1089,20 +1089,23 @@ template <int N> QPD double qp_row_shr(double v) {
   return __hiloint2double(hi, lo);
 }
 #endif
-/* The pivot of a column after rank r of a sweep is d_0 + p_0 + ... + p_r.  The sweeps add the p's as a prefix TREE over the 16 lanes of a DPP
- * row (four steps); this is the same sum taken the way the reference takes it, rank after rank: d_r = d_{r-1} + p_r, fifteen dependent
- * steps.  Same value in exact arithmetic -- but when downdates take a pivot through (almost) zero on an INDEFINITE factor, the tree's
- * partial sums of p's alone are large next to the running pivot, their rounding error is relative to them and not to it, and the factor
- * never recovers from it the way the sequential form does (round 5, fuzz case 682 / 1: D to 7e-7 instead of 2e-10 five iterations after
- * a pivot of 3.6e-5; the solve then needs 13 339 instead of 2459 iterations).  Used for nonconvex QPs (QpShared::seq_ranks). */
-template <int KG> QPD double qp_rank_prefix_seq(const double p, const int ln) {
-  double incl = p;
+/* The pivot of a column after rank r of a sweep is d_0 + p_0 + ... + p_r.  The sweeps take it as d_0 + prefix_tree(p) over the 16 lanes of a
+ * DPP row (four steps); this is the RUNNING pivot the reference computes, rank after rank: d_r = d_{r-1} + p_r, starting from d_0 (fifteen
+ * dependent steps).  Same value in exact arithmetic -- but when downdates take a pivot towards zero, the sum of the p's alone is as large
+ * as d_0, its rounding error (eps |d_0|) lands on a result that may be 1e-9 |d_0|, and gamma = w / d_new carries it into the whole column;
+ * the running pivot shrinks WITH the partial sums, so each addition rounds relative to what is left.  Round 5: fuzz case 682 / 1 (an
+ * indefinite factor polluted to 7e-7 for two hundred iterations: 13 339 iterations where the oracle needs 2459) and the LP case 701 / 128
+ * (fifty rows leaving at once, lambda_min(H) -> 1e-7: backward error of the update 1.4e-8 against 7e-16).  Used for QPs whose factor can
+ * get near-singular (QpShared::seq_ranks: nonconvex, or Q without a positive diagonal).  Returns d_new of this lane's rank; lanes of ranks
+ * that are not in the sweep carry p = 0 and pass the pivot on. */
+template <int KG> QPD double qp_rank_pivots_seq(const double p, const int ln, const double d0) {
+  double run = d0 + p; /* rank 0's; the other lanes are overwritten below */
 #pragma unroll
   for (int sq = 1; sq < KG; sq++) {
-    const double up = qp_row_shr<1>(incl);
-    if ((ln & 15) == sq) incl = up + p;
+    const double up = qp_row_shr<1>(run);
+    if ((ln & 15) == sq) run = up + p;
   }
-  return incl;
+  return run;
 }
 
 
@@ -1613,17 +1616,20 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             const double wv = (rk < kkg) ? wt[(16 * g + rk) & (K - 1)] : 0.0;
             if (QP_PANEL_TIMING == 2 && g == 0) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
             const double p = sg[g] * wv * wv * ialpha[g];
-            double incl = p;
-            if (seq) { /* d_r = d_{r-1} + p_r, rank after rank: see qp_rank_prefix_seq */
-              incl = qp_rank_prefix_seq<KG>(p, ln);
+            double dnew, dprev;
+            if (seq) { /* the running pivot, rank after rank: see qp_rank_pivots_seq */
+              dnew = qp_rank_pivots_seq<KG>(p, ln, d0);
+              const double sh = qp_row_shr<1>(dnew);
+              dprev = ((ln & 15) == 0) ? d0 : sh;
             } else {
+              double incl = p;
               if (KG > 1) incl += qp_row_shr<1>(incl);
               if (KG > 2) incl += qp_row_shr<2>(incl);
               if (KG > 4) incl += qp_row_shr<4>(incl);
               if (KG > 8) incl += qp_row_shr<8>(incl);
+              const double excl = qp_row_shr<1>(incl);
+              dnew = d0 + incl; dprev = d0 + excl;
             }
-            const double excl = qp_row_shr<1>(incl);
-            const double dnew = d0 + incl, dprev = d0 + excl;
             const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
             const double gam = -sg[g] * wv * ialpha[g] * rdn;
             if (ln < KG) { QP_CWG(U, cur, c1)[16 * g + ln][0] = -wv; QP_CWG(U, cur, c1)[16 * g + ln][1] = -gam; } /* stored negated: plain FMAs below */
@@ -1812,17 +1818,20 @@ QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const in
     const double wv = (rk < kk) ? U.Wt[rk & (K - 1)] : 0.0;
     const double d0 = qp_readlane(dreg, c1);
     const double p = sg * wv * wv * ialpha;
-    double incl = p;
+    double dnew, dprev;
     if (seq) {
-      incl = qp_rank_prefix_seq<K>(p, ln);
+      dnew = qp_rank_pivots_seq<K>(p, ln, d0);
+      const double sh = qp_row_shr<1>(dnew);
+      dprev = ((ln & 15) == 0) ? d0 : sh;
     } else {
+      double incl = p;
       if (K > 1) incl += qp_row_shr<1>(incl);
       if (K > 2) incl += qp_row_shr<2>(incl);
       if (K > 4) incl += qp_row_shr<4>(incl);
       if (K > 8) incl += qp_row_shr<8>(incl);
+      const double excl = qp_row_shr<1>(incl);
+      dnew = d0 + incl; dprev = d0 + excl;
     }
-    const double excl = qp_row_shr<1>(incl);
-    const double dnew = d0 + incl, dprev = d0 + excl;
     const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
     const double gam = -sg * wv * ialpha * rdn;
     if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; }

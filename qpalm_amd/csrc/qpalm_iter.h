@@ -257,7 +257,7 @@ QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, doub
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
   /* QPs whose factor can get near-singular (nonconvex: indefinite; an LP or a Q with an empty diagonal: pivots down to 1 / gamma): the pivots of
-   * a sweep are summed rank after rank as the reference does, not as a prefix tree (qp_rank_prefix_seq, qpalm_dense.h; option sequential_rank_sums) */
+   * a sweep are summed rank after rank as the reference does, not as a prefix tree (qp_rank_pivots_seq, qpalm_dense.h; option sequential_rank_sums) */
   __syncthreads();
   if (threadIdx.x == 0) S.seq_ranks = V.seq_mode > 0 || (V.seq_mode < 0 && (V.sc[b].nc_flag != 0 || V.sc[b].seq_hint != 0));
   __syncthreads();
