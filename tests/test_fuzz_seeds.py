@@ -191,7 +191,7 @@ def test_round5_indefinite_factor_recovers_from_a_near_zero_pivot(ctx):
     nonconvex QP with n = 224 that the oracle and twenty variants of it solve in 2426-2459 iterations took the engine 13 339 (same stationary
     point; status MAX_ITER at 10 000) -- on one workgroup, in coop mode and on round 4's library alike.  At iteration 200 twenty
     downdates take a pivot to 3.6e-5; the sweeps' tree-order prefix sum of the ranks' contributions left the factor wrong by 7e-7 from
-    there to the next refactorisation.  Nonconvex QPs now sum rank after rank (qpalm_dense.h: qp_rank_prefix_seq): 2346 iterations."""
+    there to the next refactorisation.  Nonconvex QPs now carry the running pivot rank after rank (qpalm_dense.h: qp_rank_pivots_seq): about the oracle's count."""
     if ctx.kind == "emu":
         pytest.skip("2400 iterations at n = 224: minutes in the emulator; runs on the hardware")
     for it, p, st, warm, meta in cases(682, 2, 130, 600, dict(factorization_method=1, nonconvex=1, q_shift=1.0)):

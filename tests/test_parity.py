@@ -787,3 +787,41 @@ def test_linesearch_sort_buffer_in_hbm_with_lds_tiles(ctx):
         ctx.set_option("linesearch_hbm", 0)
     for hbm in (1, 32):
         assert np.array_equal(out[0][0], out[hbm][0]) and np.array_equal(out[0][1], out[hbm][1]), hbm
+
+
+def test_downdate_into_a_numerically_singular_matrix_is_backward_stable(ctx):
+    """Round 5, fuzz LP case 701 / 128 boiled down: H = A' Sigma A + I / gamma with gamma = 1e7 and sigma = 1e3; 86 of the 90 active rows
+    leave at once (six sweeps of 16 ranks), lambda_min goes from 150 to 1e-7.  With the sweep's pivots taken as d_0 + sum(p) the factor
+    that comes out has a backward error of 2e-8; carried as the running pivot d_r = d_{r-1} + p_r (qp_rank_pivots_seq, chosen by the
+    library for QPs whose Q has no positive diagonal) it is backward stable -- both forms run here, the second must stay below 1e-13."""
+    n, m = 40, 120
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, scaling=0, gamma_init=1e7, gamma_max=1e7, sigma_init=1e3)
+    err = {}
+    try:
+        for mode in (0, -1):
+            ctx.set_option("sequential_rank_sums", mode)
+            p = random_qp(n, m, seed=9100, density_A=0.08, density_M=0.05)
+            p.Qx[:] = 0.0                                     # an LP: the engine's setup flags it (seq_hint)
+            bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+            bt.begin_solve()
+            bt.iterate(2)                                     # sigma and A' sqrt(Sigma) are set up by the first iterations
+            A = sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n)).toarray()
+            act = np.zeros(m, dtype=np.int64); act[:90] = 1
+            bt.set_ivec("active", act)
+            bt.op("ldlcholQAtsigmaA")
+            leave = np.where(act == 1)[0][2:88]
+            bt.set_ivec("leave", leave); bt.set_scalar("nb_leave", len(leave)); bt.set_scalar("nb_enter", 0)
+            bt.op("ldldowndate_leaving_constraints")
+            L, D = bt.factor(0)
+            L = np.tril(L, -1) + np.eye(n)
+            keep = act.copy(); keep[leave] = 0
+            sig, gam = bt.vec("sigma", 0)[:m], float(bt.stats(0).gamma)
+            H = (A[keep == 1].T * sig[keep == 1]) @ A[keep == 1] + np.eye(n) / gam
+            H0 = (A[act == 1].T * sig[act == 1]) @ A[act == 1] + np.eye(n) / gam
+            assert np.min(np.linalg.eigvalsh(H)) < 1e-8 * np.min(np.linalg.eigvalsh(H0))
+            err[mode] = np.max(np.abs(L @ np.diag(D) @ L.T - H)) / np.max(np.abs(H0))
+            bt.close()
+    finally:
+        ctx.set_option("sequential_rank_sums", -1)
+    assert err[-1] <= 1e-13, err
+    assert err[0] >= 1e-10, err          # (what the prefix-tree form loses on this matrix: the reason for the option)
