@@ -118,7 +118,9 @@ def parse_args(argv=None):
     ap.add_argument("--max-slots", type=int, default=0, help="resident factor slots = concurrent workgroups (0: library default)")
     ap.add_argument("--coop", type=int, default=-2, help="coop mode (several workgroups per QP, host-chained kernels): 1 force, 0 never, -1 automatic (default: the library's setting)")
     ap.add_argument("--coop-max-batch", type=int, default=0, help="largest batch the automatic choice runs in coop mode (0: library default)")
-    ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/scratch/ab.sh)")
+    ap.add_argument("--sequential-rank-sums", type=int, default=-2, help="pivots of an update sweep as the running pivot d_r = d_{r-1} + p_r (1), as d_0 + prefix tree (0), or the library's choice (default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="any integer context option of qpg_ctx_set_option (A/B runs)")
+    ap.add_argument("--lib", default=None, help="A/B runs: path of another HIP build of the library (tools/evidence/gpu_ab.sh)")
     ap.add_argument("--traffic-json", default=None,
                     help="PMC summary written by tools/evidence/round_artifacts.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                          "command on the same box).  Without it roofline.traffic is null: a plain run measures no counters.  With it, "
@@ -477,6 +479,11 @@ def worker(args):
         ctx.set_option("place_panel_wave", args.place_panel_wave)
     if not args.narrow_rows:
         ctx.set_option("narrow_rows", 0)
+    if args.sequential_rank_sums > -2:
+        ctx.set_option("sequential_rank_sums", args.sequential_rank_sums)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        ctx.set_option(name, int(val))
     B = args.batch
     if args.workload.startswith("sparse-"):
         return sparse_workload(args, ctx, rank, world, dist, torch)
@@ -661,6 +668,11 @@ def worker(args):
             "solve_stats": {"all_solved": n_bad == 0, "kkt_spot_check_worst_rel": kkt, "solution_sha256_16": sol_hash,
                             "iter_mean": float(iters.mean()), "iter_max": int(iters.max()),
                             "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve", "sweep_entries")},
+                            # the update sweeps' per-column guard (qp_rank_pivots): columns summed again as the reference's running pivot because a pivot
+                            # shrank by 2^8 or more inside a sweep, out of all columns of the diagonal-block recurrences; Newton steps redone with a
+                            # fresh factorisation because the direction out of an updated factor was not finite
+                            "pivot_guard": {"columns_resummed": int(sum(int(s.n_seq_columns) for s in stats)), "columns": int(sum(int(s.n_sweep_columns) for s in stats)),
+                                            "newton_steps_redone": int(sum(int(s.n_guard_refactor) for s in stats))},
                             "phase_ms_per_qp": phase_ms},
         }
         if world == 1 and args.workload == "random-1000" and not args.no_mpc and not args.kkt and not args.n and not args.lib:

@@ -118,6 +118,9 @@ typedef struct {
                                     that CU << 8 | panel wavefront << 4 | SIMD of wavefront 0 (qp_place_panel_wave) */
   qpg_int lobpcg_iter, nonconvex; /* LOBPCG iterations; settings->nonconvex of THIS QP after set_settings_nonconvex (:171-183) */
   qpg_int n_fused_solve;         /* of n_solve: solves whose forward substitution was done by the last update sweep (L read once, not twice) */
+  qpg_int n_seq_columns;         /* columns of the update sweeps whose pivots the per-column guard re-summed as the reference's running pivot (a pivot shrank by 2^8 or more) */
+  qpg_int n_sweep_columns;       /* ... out of this many columns of diagonal-block recurrences */
+  qpg_int n_guard_refactor;      /* Newton steps redone with a fresh factorisation because the direction from an updated factor was not finite */
 } QPGStats;
 
 typedef struct qpg_ctx qpg_ctx;

@@ -103,6 +103,13 @@ struct oq_workspace {
   /* statistics */
   oq_int n_refactor, n_factor_Q, n_updown_calls, n_rank1, n_solve, n_sigma_updates, n_boost_gamma;
   oq_int last_fact;
+  /* NOT in the reference (stated deviation, restated by the engine: qpalm_iter.h, dev_solve): a Newton step whose direction comes out of an
+   * UPDATED factor and is not finite (eta or beta of the line search is not finite: a pivot went through zero inside an update), or whose
+   * update left a pivot that is not > 0 in a convex QP (the matrix is positive definite: the factor has broken down), is taken again with
+   * a fresh factorisation.  The reference iterates on (solver_interface.c:357-368 looks at c->status only when !DLONG); on such a case
+   * its iterates are NaN to max_iter.  guard = 0 (oq_set_scalar "newton_guard") restates the reference without it. */
+  int guard, pivot_bad;
+  oq_int n_guard_refactor;
   oq_trace *trace;
 };
 
@@ -614,6 +621,7 @@ oq_workspace *oq_setup(oq_int n_, oq_int m_, const oq_int *Qp, const oq_int *Qi,
   if (!validate_settings(settings)) return NULL;
   oq_workspace *w = (oq_workspace *)calloc(1, sizeof(oq_workspace));
   if (!w) return NULL;
+  w->guard = 1;
   tic(w);
   w->settings = *settings;
   w->sqrt_delta = sqrt(w->settings.delta);
@@ -751,6 +759,7 @@ static void initialize_sigma(oq_workspace *w) { /* iteration.c:50-84 */
   sp_scale_col(&w->At_sqrt_sigma, w->At_scale);
 }
 
+static int factor_has_bad_pivot(const oq_workspace *w);
 void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
   size_t m = (size_t)w->m;
   const oq_settings *st = &w->settings;
@@ -802,6 +811,7 @@ void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
     /* nothing */
   } else {
     oq_ldlupdate_sigma_changed(w);
+    if (factor_has_bad_pivot(w)) w->reset_newton = 1; /* NOT in the reference (oq_workspace::guard): the factor broke down in this update */
   }
 }
 
@@ -1262,19 +1272,8 @@ static void kkt_matvec(oq_workspace *w, const oq_float *x, oq_float *y) {
   }
 }
 
-static void kkt_newton_direction(oq_workspace *w) { /* newton.c:22-95 */
-  const oq_settings *st = &w->settings;
+static void kkt_solve_refine(oq_workspace *w) { /* newton.c:47-95: kkt_solve + at most three refinement passes */
   const oq_int n = w->n, m = w->m, np = n + m;
-  if (w->first_factorization) {
-    kkt_form_and_factor(w); w->first_factorization = 0; w->n_refactor++; w->last_fact = 1;
-  } else if (w->reset_newton ||
-             (w->nb_enter + w->nb_leave) > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), st->max_rank_update)) {
-    kkt_form_and_factor(w); w->n_refactor++; w->last_fact = 1;
-  } else {
-    w->last_fact = 0;
-    for (oq_int e = 0; e < w->nb_enter; e++) { kkt_row_add(w, w->enter[e]); w->last_fact = 2; }
-    for (oq_int e = 0; e < w->nb_leave; e++) { kkt_row_del(w, w->leave[e]); w->last_fact = 2; }
-  }
   /* kkt_solve, solver_interface.c:238-247 */
   for (oq_int j = 0; j < n; j++) w->rhs_kkt[j] = w->dphi[j] * -1;
   for (oq_int k = 0; k < m; k++) w->rhs_kkt[n + k] = 0;
@@ -1305,9 +1304,30 @@ static void kkt_newton_direction(oq_workspace *w) { /* newton.c:22-95 */
     w->n_refine++;
   }
 }
+static void kkt_newton_direction(oq_workspace *w) { /* newton.c:22-95 */
+  const oq_settings *st = &w->settings;
+  if (w->first_factorization) {
+    kkt_form_and_factor(w); w->first_factorization = 0; w->n_refactor++; w->last_fact = 1;
+  } else if (w->reset_newton ||
+             (w->nb_enter + w->nb_leave) > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), st->max_rank_update)) {
+    kkt_form_and_factor(w); w->n_refactor++; w->last_fact = 1;
+  } else {
+    w->last_fact = 0;
+    for (oq_int e = 0; e < w->nb_enter; e++) { kkt_row_add(w, w->enter[e]); w->last_fact = 2; }
+    for (oq_int e = 0; e < w->nb_leave; e++) { kkt_row_del(w, w->leave[e]); w->last_fact = 2; }
+  }
+  kkt_solve_refine(w);
+}
 
+/* the guard's second trigger (see oq_workspace::guard): after the updates of a step, a pivot of a convex QP's Schur factor that is not > 0 */
+static int factor_has_bad_pivot(const oq_workspace *w) {
+  if (!w->guard || w->settings.nonconvex || w->sparse_mode || w->kkt_mode) return 0;
+  for (oq_int j = 0; j < w->n; j++) if (!(w->LD.D[j] > 0)) return 1;
+  return 0;
+}
 void oq_newton_set_direction(oq_workspace *w) { /* newton.c:17-120 */
   const oq_settings *st = &w->settings;
+  w->pivot_bad = 0;
   oq_set_active_constraints(w);
   oq_set_entering_leaving_constraints(w);
   if (w->kkt_mode) {
@@ -1325,6 +1345,7 @@ void oq_newton_set_direction(oq_workspace *w) { /* newton.c:17-120 */
     w->last_fact = 0;
     if (w->nb_enter) { oq_ldlupdate_entering_constraints(w); w->last_fact = 2; }
     if (w->nb_leave) { oq_ldldowndate_leaving_constraints(w); w->last_fact = 2; }
+    if (w->last_fact == 2) w->pivot_bad = factor_has_bad_pivot(w);
   } else {
     oq_ldlchol(&w->Q, w); w->n_factor_Q++; w->last_fact = 3; /* B7 */
   }
@@ -1399,6 +1420,15 @@ void oq_update_primal_iterate(oq_workspace *w) { /* iteration.c:213-229 */
   size_t n = (size_t)w->n, m = (size_t)w->m;
   oq_newton_set_direction(w);
   w->tau = oq_exact_linesearch(w);
+  if (w->guard && (w->last_fact == 0 || w->last_fact == 2) && (!isfinite(w->eta) || !isfinite(w->beta) || w->pivot_bad)) {
+    /* NOT in the reference (oq_workspace::guard): the step is taken again with a fresh factorisation; the active sets and the
+     * enter / leave counts of the step stay as they are (they are read again by the loop, B4) */
+    w->n_guard_refactor++;
+    if (w->kkt_mode) { kkt_form_and_factor(w); w->n_refactor++; w->last_fact = 1; kkt_solve_refine(w); }
+    else { oq_ldlcholQAtsigmaA(w); w->n_refactor++; w->last_fact = 1; oq_ldlsolveLD_neg_dphi(w); }
+    w->pivot_bad = 0;
+    w->tau = oq_exact_linesearch(w);
+  }
   vec_cp(w->x, w->x_prev, n);
   vec_cp(w->dphi, w->dphi_prev, n);
   oq_vec_add_scaled(w->x, w->d, w->x, w->tau, n);
@@ -1813,6 +1843,7 @@ void oq_set_scalar(oq_workspace *w, const char *name, oq_float v) {
   else if (!strcmp(name, "tau")) w->tau = v;
   else if (!strcmp(name, "proximal")) w->settings.proximal = (oq_int)v;
   else if (!strcmp(name, "reset_newton")) w->reset_newton = (int)v;
+  else if (!strcmp(name, "newton_guard")) w->guard = (v != 0); /* 0: the reference's behaviour, no guard against a non-finite Newton direction (oq_workspace::guard) */
   else if (!strcmp(name, "sparse_mode")) w->sparse_mode = (v != 0 && !w->kkt_mode && !w->settings.enable_dual_termination) ? (int)v : 0; /* before the first solve; 1 = path
                                                          updates where they pay (the engine's rule), 2 = every change refactorises (what pins the mode against the dense one) */
   else if (!strcmp(name, "eps_abs_in")) w->eps_abs_in = v;
@@ -1830,6 +1861,7 @@ oq_int oq_get_counter(const oq_workspace *w, const char *name) {
   if (!strcmp(name, "n_row_add")) return w->n_row_add;
   if (!strcmp(name, "n_row_del")) return w->n_row_del;
   if (!strcmp(name, "n_refine")) return w->n_refine;
+  if (!strcmp(name, "n_guard_refactor")) return w->n_guard_refactor;
   if (!strcmp(name, "n_lobpcg_iter")) return w->n_lobpcg_iter;
   if (!strcmp(name, "nonconvex")) return w->settings.nonconvex;
   if (!strcmp(name, "kkt_mode")) return w->kkt_mode;

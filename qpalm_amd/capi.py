@@ -49,7 +49,8 @@ class Stats(C.Structure):
                [(k, c_float) for k in ("gamma", "tau", "eta", "beta", "eps_pri", "eps_dua", "eps_dua_in", "sc_c",
                                        "ms_total", "ms_factor", "ms_update", "ms_solve", "ms_linesearch")] + \
                [("ms_dbg", c_float * 16), ("sweep_entries", c_int), ("factor_reread_entries", c_int),
-                ("lobpcg_lambda", c_float), ("placement", c_int), ("lobpcg_iter", c_int), ("nonconvex", c_int), ("n_fused_solve", c_int)]
+                ("lobpcg_lambda", c_float), ("placement", c_int), ("lobpcg_iter", c_int), ("nonconvex", c_int), ("n_fused_solve", c_int),
+                ("n_seq_columns", c_int), ("n_sweep_columns", c_int), ("n_guard_refactor", c_int)]
 
 
 class QpgError(RuntimeError):

@@ -1107,6 +1107,28 @@ template <int KG> QPD double qp_rank_pivots_seq(const double p, const int ln, co
   }
   return run;
 }
+/* d_new (after this lane's rank) and d_prev (before it) of one rank group in one column; lane & 15 = rank, every 16-lane row of the wavefront holds the
+ * same values.  mode: QP_PIV_* (qpalm_device.h).  Guarded tree: the tree's error in d_r is eps max(|d_0|, |partial sums|), the running pivot's is
+ * eps |d_r|; they differ only where |d_r| << |d_0|, so a column in which some |d_r| < 2^-8 |d_0| (or is NaN) is summed again the reference's way.
+ * The tree's result elsewhere carries at most 2^8 eps = 3e-14 of relative error in a pivot.  Returns 1 if the column was re-summed. */
+template <int KG> QPD int qp_rank_pivots(const double p, const int ln, const double d0, const int mode, double &dnew, double &dprev) {
+  if (mode != QP_PIV_SEQ) {
+    double incl = p;
+    if (KG > 1) incl += qp_row_shr<1>(incl);
+    if (KG > 2) incl += qp_row_shr<2>(incl);
+    if (KG > 4) incl += qp_row_shr<4>(incl);
+    if (KG > 8) incl += qp_row_shr<8>(incl);
+    const double excl = qp_row_shr<1>(incl);
+    dnew = d0 + incl; dprev = d0 + excl;
+    if (mode == QP_PIV_TREE) return 0;
+    const bool danger = !(__builtin_fabs(dnew) >= 0x1p-8 * __builtin_fabs(d0)); /* (a NaN compares false: danger) */
+    if (__ballot(danger ? 1 : 0) == 0ull) return 0;
+  }
+  dnew = qp_rank_pivots_seq<KG>(p, ln, d0);
+  const double sh = qp_row_shr<1>(dnew);
+  dprev = ((ln & 15) == 0) ? d0 : sh;
+  return (mode != QP_PIV_SEQ) ? 1 : 0;
+}
 
 
 /* lane R of every row of 16 lanes to all lanes of that row (DPP row_newbcast:R): no LDS, no SGPR */
@@ -1219,7 +1241,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
   /* pre_jmin >= 0: ONE rank whose dense vector the caller has already written to Wst[0 .. n) (first nonzero at
    * pre_jmin), sign +1 if n_up == 1 else -1: the trailing update of a KKT row addition / deletion */
   const int pre_jmin = QP_UNIFORM(pre_jmin_);
-  const bool seq = QP_UNIFORM(S_->seq_ranks) != 0; /* (set by dev_updown behind a barrier) */
+  const int pivmode = QP_UNIFORM(S_->seq_ranks); /* QP_PIV_* (set by dev_updown behind a barrier) */
   /* fs != NULL: the LAST sweep also does the forward substitution L y = b of the solve that follows (same ascending
    * column order: an entry of L is used for the substitution right after its last rank has been applied, so the panel
    * is not streamed a second time for it).  In: b, out: y.  The sweep then starts at column 0. */
@@ -1617,19 +1639,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
             if (QP_PANEL_TIMING == 2 && g == 0) { QP_DRAIN_LDS(); const long long t = QP_CLOCK(); if (lane == 0) tdbg[8] += t - tc0; tc0 = t; }
             const double p = sg[g] * wv * wv * ialpha[g];
             double dnew, dprev;
-            if (seq) { /* the running pivot, rank after rank: see qp_rank_pivots_seq */
-              dnew = qp_rank_pivots_seq<KG>(p, ln, d0);
-              const double sh = qp_row_shr<1>(dnew);
-              dprev = ((ln & 15) == 0) ? d0 : sh;
-            } else {
-              double incl = p;
-              if (KG > 1) incl += qp_row_shr<1>(incl);
-              if (KG > 2) incl += qp_row_shr<2>(incl);
-              if (KG > 4) incl += qp_row_shr<4>(incl);
-              if (KG > 8) incl += qp_row_shr<8>(incl);
-              const double excl = qp_row_shr<1>(incl);
-              dnew = d0 + incl; dprev = d0 + excl;
-            }
+            if (qp_rank_pivots<KG>(p, ln, d0, pivmode, dnew, dprev) && lane == 0) tdbg[QPG_CNT_SEQ_COLS] += 1; /* (rare: the guard re-summed this column) */
             const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
             const double gam = -sg[g] * wv * ialpha[g] * rdn;
             if (ln < KG) { QP_CWG(U, cur, c1)[16 * g + ln][0] = -wv; QP_CWG(U, cur, c1)[16 * g + ln][1] = -gam; } /* stored negated: plain FMAs below */
@@ -1695,6 +1705,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           QP_SCHED_BARRIER();
         }
         if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[9] += QP_CLOCK() - tp1;
+        if (lane < jb && !(dreg > 0.0)) S.pivot_bad = 1; /* (rare) a pivot that is not > 0: the caller knows whether that is a breakdown (convex QP) */
         const long long tp2 = QP_CLOCK();
         if (fuse) { /* the diagonal block is final: y_J = L_JJ^{-1} (b_J - contributions of the earlier blocks) */
           double v = accp;
@@ -1724,7 +1735,7 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) acc[rr] = own_live0 ? U.stash_acc[rr][lane] : 0.0;
         QP_SETPRIO(0);
-        if (lane == 0) tdbg[1] += QP_CLOCK() - tp0;
+        if (lane == 0) { tdbg[1] += QP_CLOCK() - tp0; tdbg[QPG_CNT_SWEEP_COLS] += jb; }
         if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[10] += QP_CLOCK() - tp2;
         tpe = QP_CLOCK();
       }
@@ -1801,7 +1812,7 @@ struct UpdownBigLds {
 #endif
 template <int K>
 QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const int jb, const int kk, const double sg,
-                          double (&wrow)[K], double &dreg, double &alpha, double &ialpha, const bool seq = false) {
+                          double (&wrow)[K], double &dreg, double &alpha, double &ialpha, const int pivmode = QP_PIV_TREE) {
   static_assert(K == 16 || !QP_PANEL_DPP, "the DPP form needs one rank per lane of a 16-lane row");
   double lnext = (lane > 0 && lane < jb) ? U.Ld[lane][0] : 0.0;
 #pragma unroll 1
@@ -1819,19 +1830,7 @@ QPD void updown_big_panel(UpdownBigLds<K> QP_LDS_AS &U, const int lane, const in
     const double d0 = qp_readlane(dreg, c1);
     const double p = sg * wv * wv * ialpha;
     double dnew, dprev;
-    if (seq) {
-      dnew = qp_rank_pivots_seq<K>(p, ln, d0);
-      const double sh = qp_row_shr<1>(dnew);
-      dprev = ((ln & 15) == 0) ? d0 : sh;
-    } else {
-      double incl = p;
-      if (K > 1) incl += qp_row_shr<1>(incl);
-      if (K > 2) incl += qp_row_shr<2>(incl);
-      if (K > 4) incl += qp_row_shr<4>(incl);
-      if (K > 8) incl += qp_row_shr<8>(incl);
-      const double excl = qp_row_shr<1>(incl);
-      dnew = d0 + incl; dprev = d0 + excl;
-    }
+    qp_rank_pivots<K>(p, ln, d0, pivmode, dnew, dprev);
     const double rdn = qp_rcp(dnew), rdp = qp_rcp(dprev);
     const double gam = -sg * wv * ialpha * rdn;
     if (ln < K) { U.cwg[c1][ln][0] = -wv; U.cwg[c1][ln][1] = -gam; }
@@ -1914,8 +1913,9 @@ QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_
 #pragma unroll
         for (int r = 0; r < K; r++) wrow[r] = (lane < jb && r < kk) ? Wst[(size_t)r * n + J + lane] : 0.0;
         double dreg = (lane < jb) ? U.dd[lane] : 1.0;
-        updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, QP_UNIFORM(S.seq_ranks) != 0);
+        updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, QP_UNIFORM(S.seq_ranks));
         if (lane < jb) Dg[J + lane] = dreg;
+        if (lane < jb && !(dreg > 0.0)) S.pivot_bad = 1; /* (as in dense_updown) */
 #pragma unroll 1
         for (int c = 0; c < jb; c++)
           if (lane > c && lane < jb) L[(size_t)(J + c) * ld + (J + lane)] = U.Ld[lane][c];
@@ -1990,7 +1990,7 @@ QPD void co_updown_init(const int *Atp, const int *Ati, const double *Atss, cons
 /* block column J (J >= n: only the pending stage is written back) */
 template <int K>
 QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, double *Wst, double *hst, const int J, const int r0, const int kk,
-                         const int n_up, char *lds, const int wg, const int nwg, const bool seq) {
+                         const int n_up, char *lds, const int wg, const int nwg, const int pivmode) {
   typedef UpdownBigLds<K> LdsT;
   LdsT QP_LDS_AS &U = *QP_LDS_ARG(LdsT, lds);
   const int NB = QP_UNB, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -2025,7 +2025,7 @@ QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, doubl
     double alpha = (rl < K) ? hst[par * 2 * K + rl] : 1.0, ialpha = (rl < K) ? hst[par * 2 * K + K + rl] : 1.0;
     const int grank = r0 + rl;
     const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
-    updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, seq);
+    updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, pivmode);
     if (wg == 0) {
       if (lane < K) { hst[(1 - par) * 2 * K + lane] = alpha; hst[(1 - par) * 2 * K + K + lane] = ialpha; }
       if (lane < jb) hst[CO_UD_D + lane] = dreg;
@@ -2107,7 +2107,7 @@ QPD void co_updown_block(const int n, const int ld, double *L, double *Dg, doubl
 #define CO_UD_TAB(K) (QP_UNB * (K) * 2 + 2 * (K)) /* doubles per published table: the block's (-w, -gamma) pairs, then alpha and 1 / alpha per rank */
 template <int K>
 QPD void co_updown_persist(const int n, const int ld, double *L, double *Dg, const double *Wst, const double *hst, double *tab, int *flags,
-                           const int r0, const int kk, const int n_up, char *lds, const int wg, QpShared &S, const bool seq) {
+                           const int r0, const int kk, const int n_up, char *lds, const int wg, QpShared &S, const int pivmode) {
   typedef UpdownBigLds<K> LdsT;
   LdsT QP_LDS_AS &U = *QP_LDS_ARG(LdsT, lds);
   double QP_LDS_AS *wd = (double QP_LDS_AS *)(QP_LDS_ARG(char, lds) + ((sizeof(LdsT) + 15) & ~(size_t)15)); /* [NB][K]: running values of a diagonal block's rows */
@@ -2118,6 +2118,11 @@ QPD void co_updown_persist(const int n, const int ld, double *L, double *Dg, con
   const int bstart = (int)hst[CO_UD_JMIN] / NB; /* the update vectors are zero above their first entry: blocks in front of it are not touched */
   const int bown0 = R0 / NB, bown1 = (R1 + NB - 1) / NB; /* my diagonal blocks */
   if (bown1 <= bstart) return;
+  if (wg == 1 && QP_UNIFORM(QP_FLAG_LOAD(flags + 2)) != 0) { /* TEST HOOK (context option coop_test_kill): this workgroup gives up as if it had timed out */
+    __syncthreads();
+    if (tid == 0) { QP_FLAG_STORE(flags + 2, 0); QP_FLAG_STORE(flags + 1, 1 + wg); }
+    return;
+  }
   const int rt = tid - CO_UD_FIRST;
   const int i = R0 + rt;
   const bool live = rt >= 0 && rt < CO_UD_ROWS && i < n;
@@ -2141,9 +2146,12 @@ QPD void co_updown_persist(const int n, const int ld, double *L, double *Dg, con
   int next = bstart;
   while (next < bown0) {
     if (tid == 0) {
-      int r = QP_FLAG_LOAD(flags);
-      for (unsigned spins = 0; r <= next && spins < (1u << 22); spins++) { QP_SLEEP(); r = QP_FLAG_LOAD(flags); }
-      if (r <= next) { QP_FLAG_STORE(flags + 1, 1 + wg); r = -1; }
+      /* bounded wait for the owner of block `next`; flags[1] != 0 = somebody in this sweep has given up: leave at once instead of waiting out a
+       * timeout of one's own behind it (the give-ups used to cascade).  The factor is then half updated: the iteration kernel sees
+       * the mark when it resumes and rebuilds the factor (dev_solve), nothing iterates on it. */
+      int r = QP_FLAG_LOAD(flags), dead = QP_FLAG_LOAD(flags + 1);
+      for (unsigned spins = 0; r <= next && dead == 0 && spins < (1u << 22); spins++) { QP_SLEEP(); r = QP_FLAG_LOAD(flags); dead = QP_FLAG_LOAD(flags + 1); }
+      if (r <= next) { if (dead == 0) QP_FLAG_STORE(flags + 1, 1 + wg); r = -1; }
       QP_ACQUIRE_AGENT();
       QP_DRAIN_VMEM();
       S.ired[0][3] = r;
@@ -2201,7 +2209,7 @@ QPD void co_updown_persist(const int n, const int ld, double *L, double *Dg, con
       }
       const int grank = r0 + rl;
       const double sg = (rl < kk) ? ((grank < n_up) ? 1.0 : -1.0) : 0.0;
-      updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, seq);
+      updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, pivmode);
       QP_WAVE_SYNC();
       if (lane < jb) Dg[J + lane] = dreg;
 #pragma unroll 1

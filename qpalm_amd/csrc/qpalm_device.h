@@ -176,10 +176,24 @@ struct QpShared {          /* small static LDS block */
   int    hw_simd[QP_NW];   /* SIMD each wavefront of this workgroup sits on */
   int    placement;        /* diagnostic code of the placement (QPGStats.placement) */
   int    panel_wave;       /* the wavefront that runs the serial chains of the update sweep (qp_place_panel_wave) */
-  int    seq_ranks;        /* update sweeps add the ranks' contributions to a pivot one after the other instead of as a prefix tree (dev_updown: nonconvex QPs) */
+  int    seq_ranks;        /* how the update sweeps sum the ranks' contributions to a pivot (QP_PIV_*, set by dev_updown from qp_pivot_mode) */
+  int    pivot_bad;        /* an update sweep of a CONVEX QP left a pivot that is not > 0 (the matrix is positive definite: the factor has broken down) */
   int    wave_rank[QP_NW]; /* the sweep's name for each hardware wavefront: 0 = panel wave (owner of the first rows), then the wavefronts that
                               sit on the SIMDs where the CU's panel waves run (they get the rows that retire first), then the rest */
 };
+
+/* How the pivots of a column after each rank of a sweep are summed (qp_rank_pivots, qpalm_dense.h).  The reference (cholmod_updown,
+ * solver_interface.c:415-421,433-439) carries the running pivot d_r = d_{r-1} + p_r rank after rank; a prefix tree d_0 + (p_0 + .. + p_r)
+ * is equal in exact arithmetic, four dependent steps instead of fifteen, and as accurate UNLESS a pivot shrinks a lot inside the sweep
+ * (then the tree's rounding error is relative to d_0, not to the pivot: DESIGN.md section 5).  One predicate for every sweep form. */
+#define QP_PIV_TREE 0  /* prefix tree, unguarded (context option sequential_rank_sums = 0: A/B runs only) */
+#define QP_PIV_SEQ 1   /* the running pivot in every column (= 1; and by itself for nonconvex QPs and QPs whose Q has a column without a positive diagonal) */
+#define QP_PIV_GUARD 2 /* the default: prefix tree, and a column in which some pivot comes out below 2^-8 of the column's pivot before the sweep (or is not
+                          finite) is summed again as running pivots -- wave-uniform, one compare per column */
+QPD int qp_pivot_mode(const qpg_view &V, int b) {
+  if (V.seq_mode > 0 || (V.seq_mode < 0 && (V.sc[b].nc_flag != 0 || V.sc[b].seq_hint != 0))) return QP_PIV_SEQ;
+  return (V.seq_mode < 0) ? QP_PIV_GUARD : QP_PIV_TREE;
+}
 
 QPD double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

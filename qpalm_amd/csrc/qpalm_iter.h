@@ -256,10 +256,10 @@ QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, doub
                     const int *dn, int n_dn, QpShared &S, char *lds, int64_t *tdbg, double *fs = nullptr, int pre_jmin = -1) {
   const int *Atp = V.Atp + (size_t)b * (V.m + 1), *Ati = V.Ati + (size_t)b * V.nnzA;
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
-  /* QPs whose factor can get near-singular (nonconvex: indefinite; an LP or a Q with an empty diagonal: pivots down to 1 / gamma): the pivots of
-   * a sweep are summed rank after rank as the reference does, not as a prefix tree (qp_rank_pivots_seq, qpalm_dense.h; option sequential_rank_sums) */
+  /* how the sweeps sum a column's pivots (qp_pivot_mode, qpalm_device.h): the running pivot of the reference throughout for QPs whose factor can get
+   * near-singular (nonconvex: indefinite; an LP or a Q with an empty diagonal: pivots down to 1 / gamma), else the guarded prefix tree */
   __syncthreads();
-  if (threadIdx.x == 0) S.seq_ranks = V.seq_mode > 0 || (V.seq_mode < 0 && (V.sc[b].nc_flag != 0 || V.sc[b].seq_hint != 0));
+  if (threadIdx.x == 0) { S.seq_ranks = qp_pivot_mode(V, b); S.pivot_bad = 0; }
   __syncthreads();
   if constexpr (RPT == 0) dense_updown_big<16>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin);
   else if constexpr (QP_K32(RPT)) {
@@ -703,7 +703,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
       I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot; I.s.pend_stage = 0; I.s.pend_clock = 0;
       I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
-      I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0; I.s.n_fused_solve = 0;
+      I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0; I.s.n_fused_solve = 0; I.s.guard_redo = 0; I.s.n_guard_refactor = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
       for (int k = 0; k < QPG_NDBG; k++) I.s.ticks_dbg[k] = 0;
       I.s.ticks_dbg[QPG_CNT_PLACEMENT] = I.S.placement;
@@ -724,10 +724,28 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     __syncthreads();
     const bool dual_init = (QP_UNIFORM(I.s.dual_pending) != 0); /* workgroup-uniform: keep the branch scalar */
     const bool resume = (QP_UNIFORM(I.s.pend_stage) != 0); /* coop mode: the host has done this iteration's factorisation / solve */
+    const bool redo = !resume && (QP_UNIFORM(I.s.guard_redo) != 0); /* the Newton step of the last pass is taken again with a fresh factorisation (the guard below) */
+    if (redo) {
+      la = V.kkt ? 8 : 1; action = 1; kind = QP_KIND_NEWTON; nchange = 0; /* the active sets and nb_enter / nb_leave of the step stay (they are read again, B4) */
+      __syncthreads();
+      if (tid == 0) I.s.guard_redo = 0;
+      __syncthreads();
+    } else
     if (resume) {
       la = I.s.pend_la; action = I.s.pend_action; kind = I.s.pend_kind; nchange = I.s.pend_nchange; gam = I.s.pend_gam;
       if (la == 4) { n_sig = nchange; nchange = 0; }
       __syncthreads();
+      /* coop mode, one-launch update sweep (co_updown_persist): a workgroup that timed out waiting for a table left its mark and the factor half
+       * updated.  Nothing iterates on that: the mark is cleared and the factor rebuilt -- a Newton step is taken again with a fresh factorisation
+       * (the guard's path below), a sigma update leaves reset_newton set. */
+      const bool sweep_died = (la == 2 || la == 4) && V.co_flags != nullptr && QP_UNIFORM(V.co_flags[(size_t)b * 4 + 1]) != 0;
+      __syncthreads();
+      if (sweep_died && tid == 0) { V.co_flags[(size_t)b * 4 + 1] = 0; I.s.n_guard_refactor++; if (la == 4) I.s.reset_newton = 1; }
+      if (sweep_died && la == 2 && kind == QP_KIND_NEWTON) {
+        if (tid == 0) { I.s.pend_stage = 0; I.s.guard_redo = 1; }
+        __syncthreads();
+        continue;
+      }
       if (tid == 0) {
         I.s.pend_stage = 0;
         /* the host's multi-workgroup kernels ran between the suspension and this launch: their time belongs to the solve */
@@ -1022,7 +1040,10 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     QP_OPAQUE(a.b);
     if (la == 4) {
       dev_update_sigma_post(a, I, n_sig);
-      if (tid == 0) { I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
+      if (tid == 0) {
+        I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0;
+        if (!resume && !SPARSE && I.s.nc_flag == 0 && I.S.pivot_bad != 0) I.s.reset_newton = 1; /* the guard above: the factor broke down in this update */
+      }
     } else if (la == 5 || la == 6) dev_boost_gamma_apply(V, a, I, gersh_ub);
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
@@ -1052,6 +1073,22 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       const double tau = dev_linesearch(V, a, I, lds);
       const long long t3 = QP_CLOCK();
       QP_OPAQUE(a.b);
+      /* NOT in the reference (stated deviation, restated by the oracle: oq_update_primal_iterate): a direction out of an UPDATED factor that is
+       * not finite (eta = d'(Q + I/gamma)d or beta = d'df: a pivot went through zero inside an update sweep), or an update that left a pivot
+       * not > 0 in a convex QP (H is positive definite: the factor has broken down), is not stepped along: the pass is taken again with a fresh
+       * factorisation.  The reference iterates on NaN to max_iter there (solver_interface.c:357-368 looks at c->status only when !DLONG).
+       * Fuzz case 701 / 114 (LP, sigma up to 1e9 against 1 / gamma = 1e-7).  Free on healthy steps: two compares on scalars the line search has. */
+      if (action == 0 || action == 2) {
+        const double ge = I.s.eta, gb = I.s.beta;
+        const bool bad = !(qabs(ge) <= 1.7976931348623157e308) || !(qabs(gb) <= 1.7976931348623157e308) ||
+                         (la == 2 && !resume && !V.kkt && !SPARSE && I.s.nc_flag == 0 && I.S.pivot_bad != 0);
+        if (QP_UNIFORM((int)bad) != 0) {
+          __syncthreads();
+          if (tid == 0) { I.s.guard_redo = 1; I.s.n_guard_refactor++; I.s.ticks_linesearch += t3 - t2; }
+          __syncthreads();
+          continue;
+        }
+      }
       /* iteration.c:219-228 */
       for (int j = tid; j < n; j += QP_T) {
         const double xv = a.x()[j];

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_co_updown(qpg_view V, int
       V.sc[b].ticks_dbg[QPG_CNT_SWEEP_ENTRIES] += (long long)(n - J0) * (n - J0 - 1) / 2 + (n - J0);
     }
   }
-  else co_updown_block<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, J, r0, kk, n_up, lds, (int)blockIdx.x, (int)gridDim.x, V.seq_mode > 0 || (V.seq_mode < 0 && (V.sc[b].nc_flag != 0 || V.sc[b].seq_hint != 0)));
+  else co_updown_block<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, J, r0, kk, n_up, lds, (int)blockIdx.x, (int)gridDim.x, qp_pivot_mode(V, b));
   if (phase == 1 && blockIdx.x == 0 && threadIdx.x == 0 && V.co_flags) V.co_flags[(size_t)b * 4] = (int)hst[CO_UD_JMIN] / QP_UNB; /* the persistent sweep's counter: blocks published so far */
 }
 /* ... and the whole sweep in ONE launch after phases 0 and 1 (co_updown_persist: one workgroup per 128 rows, at most 64 of them on the
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(QP_T) void k_co_sweep(qpg_view V, int b, int slot, 
   const int kk = (n_up + n_dn - r0 < QPG_KMAX) ? (n_up + n_dn - r0) : QPG_KMAX;
   double *L = co_slot_L(V, slot, 0), *Dg = co_slot_D(V, slot, 0), *Wst = V.Wst + (size_t)slot * V.wst_stride;
   const double *hst = Wst + (size_t)QPG_KMAX * V.nfac + QPG_DUMMY;
-  co_updown_persist<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, V.co_tab + (size_t)b * V.co_tab_stride, V.co_flags + (size_t)b * 4, r0, kk, n_up, lds, (int)blockIdx.x, S, V.seq_mode > 0 || (V.seq_mode < 0 && (V.sc[b].nc_flag != 0 || V.sc[b].seq_hint != 0)));
+  co_updown_persist<QPG_KMAX>(n, V.ld, L, Dg, Wst, hst, V.co_tab + (size_t)b * V.co_tab_stride, V.co_flags + (size_t)b * 4, r0, kk, n_up, lds, (int)blockIdx.x, S, qp_pivot_mode(V, b));
 }
 
 /* Diagnostic (tools/evidence/sweep_probe.py): every resident workgroup factorises Q + I/gamma of its QP and then applies `reps` times a

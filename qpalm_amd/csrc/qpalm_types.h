@@ -36,11 +36,13 @@ typedef struct {
 } qpg_settings;
 
 #define QPG_CU_KEYS 4096 /* 16 XCC ids x 256 (se, sh, cu) ids of HW_REG_HW_ID */
-#define QPG_NDBG 20
+#define QPG_NDBG 22
 #define QPG_CNT_SWEEP_ENTRIES 16 /* entries of L (doubles) the rank-update sweeps read AND wrote: sum of nnz(L[:, J0:]) */
 #define QPG_CNT_SWEEPS 17        /* sweeps over the panel (<= K ranks each, K = 16 or 8 by instantiation) */
 #define QPG_CNT_FACTOR_REREAD 18 /* entries of L re-read by the left-looking panel updates of the factorisation */
 #define QPG_CNT_PLACEMENT 19     /* not a counter: where the workgroup ran (QPGStats.placement) */
+#define QPG_CNT_SEQ_COLS 20      /* columns of the update sweeps whose pivots the per-column guard re-summed as running pivots (qp_rank_pivots) */
+#define QPG_CNT_SWEEP_COLS 21    /* columns the diagonal-block recurrences of the update sweeps went through (the guard's denominator) */
 /* dynamic LDS of a 512-thread workgroup: the update sweep's scratch (UpdownLds<2, 16>: 77 192 bytes); two workgroups plus
  * their static LDS fit the 160 KB of a CU */
 #define QPG_LDS_DEFAULT 77824
@@ -75,6 +77,8 @@ typedef struct {
   double pend_gam;
   int64_t pend_clock; /* device clock (100 MHz, the same counter in every launch) when the iteration was suspended: the time the host's
                          kernels take until it resumes is added to solve_time, so that run_time and time_limit see wall time (qpalm.c:680-723) */
+  int32_t guard_redo, n_guard_refactor; /* guard_redo: the Newton direction of the last pass was not finite on an UPDATED factor (a pivot went through zero inside a sweep):
+                                           the next pass refactorises and solves again instead of stepping (dev_solve; the oracle restates the same guard); the count of such passes */
   int32_t dual_pending, kkt_first; /* kkt_first: solver->first_factorization (types.h:176), KKT path; dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
   /* work counters (device side statistics for the roofline accounting in bench.py) */
   int32_t n_refactor, n_factor_Q, n_sweeps, n_rank1, n_solve, n_sigma_updates, n_boost_gamma, n_fused_solve; /* n_fused_solve: Newton solves whose forward substitution rode on the last update sweep (L streamed once less) */

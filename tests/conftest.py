@@ -60,3 +60,42 @@ def ctx(request):
     c.set_option("coop", 0)              # the one-workgroup-per-QP engine; tests/test_coop.py switches the multi-workgroup mode on
     c.set_option("coop_workgroups", 3 if kind == "emu" else 256)
     return c
+
+
+# ---- counts of the randomised campaigns in the summary (tests/test_fuzz_seeds.py: _report) --------------------------------------------------
+_FUZZ_FILE = os.path.join(ROOT, ".pytest_cache", "qpalm_fuzz_counts.jsonl")
+
+
+def fuzz_count(campaign, backend, total, failed, by_class):
+    os.makedirs(os.path.dirname(_FUZZ_FILE), exist_ok=True)
+    with open(_FUZZ_FILE, "a") as f:
+        f.write(json.dumps(dict(campaign=campaign, backend=backend, total=total, failed=failed, by_class=by_class)) + "\n")
+
+
+def pytest_sessionstart(session):
+    if not hasattr(session.config, "workerinput"):   # the controller (or the only process): a fresh file per run
+        try:
+            os.remove(_FUZZ_FILE)
+        except OSError:
+            pass
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line per randomised campaign that ran: cases, rule failures, and the accepted-but-not-exact cases by bucket (tests/fuzz_cases.py:
+    judge_case) -- `rounding` = the reference's own source changes its outcome under the compiler's flags / a one-ulp perturbation / the
+    trajectory criterion, `engine-form` = only the oracle variants restating the engine's recurrence move, `singular` = non-finite in the
+    engine and in a reference build.  Everything else matched the oracle in status, iteration count, x and y."""
+    if not os.path.exists(_FUZZ_FILE):
+        return
+    rows = [json.loads(ln) for ln in open(_FUZZ_FILE) if ln.strip()]
+    if not rows:
+        return
+    tr = terminalreporter
+    tr.write_line("fuzz campaigns (cases / rule failures / accepted as: rounding, engine-form, singular):")
+    tot = [0, 0, 0, 0, 0]
+    for r in rows:
+        b = r["by_class"]
+        v = [r["total"], r["failed"], b.get("rounding", 0), b.get("engine-form", 0), b.get("singular", 0)]
+        tot = [a + c for a, c in zip(tot, v)]
+        tr.write_line("  [%s] %-34s %5d / %d / %d, %d, %d" % (r["backend"], r["campaign"], *v))
+    tr.write_line("  fuzz total: %d cases, %d rule failures, %d rounding-decided, %d engine-form, %d singular" % tuple(tot))

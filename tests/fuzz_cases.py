@@ -92,6 +92,8 @@ def run_case(ctx, p, st, warm, oracle_sparse_mode=0):
     x, y = bt.solution()
     sig = bt.vec("sigma", 0)
     res = dict(status=(int(info.status_val), int(o.status_val)), iter=(int(info.iter), int(o.info.iter)),
+               nonfinite=(not (np.all(np.isfinite(x[0])) and np.all(np.isfinite(y[0]))), not (np.all(np.isfinite(o.x)) and np.all(np.isfinite(o.y)))),
+               guard=(int(bt.stats(0).n_guard_refactor), int(o.counter("n_guard_refactor"))),
                dx=rel(x[0], o.x), dy=rel(y[0], o.y), ymax=float(np.max(np.abs(o.y))) if o.y.size else 0.0,
                obj=(float(info.objective), float(o.info.objective)), sigma_max=float(np.max(sig)) if sig.size else 0.0,
                iter_out=int(o.info.iter_out), ybound=y_bound_from_dx(p, o, x[0] - o.x))
@@ -124,8 +126,8 @@ def oracle_variants():
     return _VARIANTS
 
 
-def oracle_outcomes(p, st, warm):
-    """{variant: (status, iter)} of the oracle variants on one case"""
+def oracle_outcomes(p, st, warm, nonfinite=None):
+    """{variant: (status, iter)} of the oracle variants on one case; nonfinite (a set, optional) collects the variants whose x or y is not finite"""
     import oracle.binding as ob
     out = {}
     for name, lib in oracle_variants().items():
@@ -134,8 +136,13 @@ def oracle_outcomes(p, st, warm):
             o.warm_start(warm[0], warm[1])
         o.solve()
         out[name] = (int(o.status_val), int(o.info.iter))
+        if nonfinite is not None and not (np.all(np.isfinite(o.x)) and np.all(np.isfinite(o.y))):
+            nonfinite.add(name)
         o.cleanup()
     return out
+
+
+ENGINE_FORM_VARIANTS = ("pivot", "pivot_plain")   # oracle variants that restate the ENGINE's form of the rank-update recurrence (OQ_PIVOT_ENGINE)
 
 
 def oracle_perturbed(p, st, warm, count=6):
@@ -160,7 +167,10 @@ def oracle_perturbed(p, st, warm, count=6):
 
 
 def judge_case(r, p, st, warm, ytol=1e-8, ctx=None):
-    """The sharp form of "parity with the oracle" for one case.  Returns (ok, why, decided_by_rounding).
+    """The sharp form of "parity with the oracle" for one case.  Returns (ok, why, cls): cls is False for a case that matches the oracle outright,
+    else the bucket the accepted case is counted in -- "rounding" (the reference's own source changes its outcome under the compiler's flags or a
+    one-ulp perturbation of the data, or the trajectory criterion holds), "engine-form" (only the oracle variants that restate the ENGINE's form
+    of the rank-update recurrence move), "singular" (non-finite iterates in the engine AND in a reference build: H singular by construction).
       * (status, iterations) equal to the plain oracle's: x within 1e-8, y within ytol of it (solved cases).
       * otherwise the case must be one whose count ROUNDING decides -- the oracle's own source, compiled with fused multiply-adds or
         -Ofast, does not reproduce the plain oracle's (status, iterations) either; or (noise_decided_branch) the two iteration paths
@@ -179,11 +189,24 @@ def judge_case(r, p, st, warm, ytol=1e-8, ctx=None):
         # whose penalty grew on the way.  (Round 4 used 100 x the engine's largest sigma x |dx|_inf, a factor fitted to one campaign.)
         ytol = min(1e-4, max(ytol, 2.0 * max(1, r.get("iter_out", 1)) * r.get("ybound", 0.0)))
         r["ytol_used"] = ytol
+        if r.get("nonfinite", (False, False)) == (True, False):
+            return False, "same status and count, but the engine's iterate is NOT FINITE and the oracle's is", False
         if r["status"][1] in (1, 2) and not (r["dx"] <= 1e-8 and r["dy"] <= ytol):
             return False, "same count, x / y differ: dx %.3e dy %.3e (y bound %.3e)" % (r["dx"], r["dy"], ytol), False
         return True, "", False
-    var = oracle_outcomes(p, st, warm)
+    nonfin = set()
+    var = oracle_outcomes(p, st, warm, nonfin)
     plain = (r["status"][1], r["iter"][1])
+    if r.get("nonfinite", (False, False))[0]:
+        # Round 6: an engine iterate that is NOT FINITE is never "rounding".  Either the reference's own arithmetic does the same
+        # on this case -- the plain oracle or its FMA / -Ofast build (NOT the variants that restate the engine's formulas) ends with a
+        # non-finite iterate and the engine's status: H is singular by construction (an LP without the proximal term and fewer active rows
+        # than variables: the factorisation divides by a pivot that is zero up to rounding) and there is no behaviour to match -- or it fails.
+        ref_nonfin = (nonfin - set(ENGINE_FORM_VARIANTS)) | ({"plain"} if r["nonfinite"][1] else set())
+        same_status = [k for k in ref_nonfin if (plain if k == "plain" else var[k])[0] == r["status"][0]]
+        if same_status:
+            return True, "singular H: engine %s not finite, like the oracle build(s) %s; plain %s, variants %s" % ((r["status"][0], r["iter"][0]), sorted(same_status), plain, var), "singular"
+        return False, "engine iterate NOT FINITE (%s) where the plain oracle %s and its FMA / -Ofast builds %s stay finite" % ((r["status"][0], r["iter"][0]), plain, var), False
     if all(v == plain for v in var.values()):
         # no compiler-flag / formula variant flipped: is the count stable under a one-ulp perturbation of the DATA?  (If it is not, no
         # implementation with another -- equally valid -- rounding can be expected to reproduce it.)
@@ -202,7 +225,11 @@ def judge_case(r, p, st, warm, ytol=1e-8, ctx=None):
         tol = 10.0 * max(st["eps_abs"], st["eps_rel"])
         if abs(r["obj"][0] - r["obj"][1]) > tol * max(1.0, abs(r["obj"][1])):
             return False, "rounding-decided case, but the objectives differ: %r" % (r["obj"],), True
-    return True, "rounding-decided: engine %s, oracle %s, variants %s" % ((r["status"][0], r["iter"][0]), plain, var), True
+    moved = {k for k, v in var.items() if k != "trajectory" and v != plain}
+    # the variants that restate the engine's own recurrence are a bucket of their own: they show that a count depends on how
+    # that recurrence is rounded, which is weaker than the reference's source changing its count under the compiler's flags
+    cls = "engine-form" if (moved and moved <= set(ENGINE_FORM_VARIANTS)) else "rounding"
+    return True, "%s: engine %s, oracle %s, variants %s" % ("rounding-decided" if cls == "rounding" else "decided by the form of the rank-update recurrence", (r["status"][0], r["iter"][0]), plain, var), cls
 
 
 def noise_decided_branch(ctx, p, st, warm, cap=3000):

@@ -90,6 +90,41 @@ def test_coop_update_sweep_in_one_launch_equals_the_chain_of_launches(ctx):
     b1.close()
 
 
+def test_coop_update_sweep_survives_a_workgroup_that_gives_up(ctx):
+    """a workgroup of the one-launch sweep that gives up waiting for a table (bounded spin) used to return with the factor half
+    updated, every later workgroup waited out a timeout of its own, and the solver iterated on the corrupt factor until the host looked at
+    the mark after the WHOLE solve.  Now the mark makes the workgroups behind it leave at once, and the iteration kernel that resumes after
+    the sweep sees it, clears it and takes the Newton step again with a fresh factorisation.  The test hook `coop_test_kill = N` makes the
+    second workgroup of the N-th sweep of the solve give up at once: the solve must still end SOLVED at the oracle's solution, with the
+    rebuilt factor counted (n_guard_refactor), and the next solve of the same batch must not see a stale mark."""
+    n, m = sizes(ctx, (260, 300), (700, 1400))
+    p = random_qp(n, m, seed=4242, density_A=0.01 if n >= 400 else 4.0 / n, density_M=0.005 if n >= 400 else 2.0 / n)
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0)
+    o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
+    o.solve()
+    ctx.set_option("coop", 1)
+    ctx.set_option("coop_rank_threshold", -1)   # the reference's refactorise-or-update rule: rank updates at this size
+    try:
+        ctx.set_option("coop_test_kill", 2)
+        bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+        bt.solve()
+        x, y = bt.solution()
+        assert int(bt.info(0).status_val) == 1 and int(bt.stats(0).n_guard_refactor) == 1, (bt.info(0).status_val, bt.stats(0).n_guard_refactor)
+        assert rel(x[0], o.x) <= 1e-8 and rel(y[0], o.y) <= 1e-8
+        assert int(bt.info(0).iter) == int(o.info.iter)            # the rebuilt factor is that of the same matrix: the path does not change
+        ctx.set_option("coop_test_kill", 0)
+        bt.warm_start(None, None)
+        bt.solve()
+        x2, y2 = bt.solution()
+        assert int(bt.info(0).status_val) == 1 and int(bt.stats(0).n_guard_refactor) == 0
+        assert rel(x2[0], o.x) <= RTOL and rel(y2[0], o.y) <= RTOL and int(bt.info(0).iter) == int(o.info.iter)
+        bt.close()
+    finally:
+        ctx.set_option("coop_test_kill", 0)
+        ctx.set_option("coop_rank_threshold", -2)
+        ctx.set_option("coop", 0)
+
+
 def test_coop_members_of_different_sizes_and_repeated_solves(ctx):
     """two QPs of different sizes in one coop batch, solved three times (on the GPU the launch chains of each member are recorded
     during the second solve and replayed as graphs in the third): every solve against the oracle"""

@@ -31,12 +31,24 @@ def _campaign(ctx, seed, count, n_lo, n_hi, force=None):
     bad, soft = [], []
     for it, p, st, warm, meta in cases(seed, count, n_lo, n_hi, force):
         r = run_case(ctx, p, st, warm)
-        ok, why, rounding = judge_case(r, p, st, warm, 1e-8, ctx)
+        ok, why, cls = judge_case(r, p, st, warm, 1e-8, ctx)
         if not ok:
             bad.append((seed, it, meta, {k: st[k] for k in ("factorization_method", "sigma_init", "scaling", "proximal")}, why))
-        elif rounding:
-            soft.append((seed, it, why))
+        elif cls:
+            soft.append((seed, it, why, cls))
     return bad, soft
+
+
+def _report(ctx, campaign, total, bad, soft):
+    """the campaign's counts into the pytest summary (tests/conftest.py: pytest_terminal_summary), so that the accepted-but-not-exact cases
+    are visible in the driver's record and not only in the builder's logs"""
+    from tests.conftest import fuzz_count
+    by = {}
+    for t in soft:
+        cls = t[-1] if isinstance(t[-1], str) else "rounding"
+        by[cls] = by.get(cls, 0) + 1
+    fuzz_count(campaign, ctx.kind, total, len(bad), by)
+    return by
 
 
 def test_fuzz_general_campaign(ctx):
@@ -45,6 +57,7 @@ def test_fuzz_general_campaign(ctx):
     for seed, count, n_lo, n_hi in plan:   # 2..70: the 256-thread instance; 257..420: the 512-thread instance, KKT panels up to ~1100 rows
         b, s = _campaign(ctx, seed, count, n_lo, n_hi)
         bad += b; soft += s; total += count
+    _report(ctx, "G general", total, bad, soft)
     assert not bad, bad
     assert len(soft) <= max(1, total // 100), soft   # rounding-decided cases are rare (round 3: 5 of 1960 fresh cases)
 
@@ -62,6 +75,7 @@ def test_fuzz_general_campaign_on_the_128_thread_instance(ctx):
             bad += b; soft += s; total += count
     finally:
         ctx.set_option("small_workgroups", 1)
+    _report(ctx, "T general, 128-thread instance", total, bad, soft)
     assert not bad, bad
     assert len(soft) <= max(1, total // 100), soft
 
@@ -73,6 +87,7 @@ def test_fuzz_kkt_with_large_sigma(ctx):
     for seed, count, n_lo, n_hi in plan:
         b, s = _campaign(ctx, seed, count, n_lo, n_hi, force)
         bad += b; soft += s; total += count
+    _report(ctx, "K KKT, sigma_init 1e3", total, bad, soft)
     assert not bad, bad
     assert len(soft) <= max(1, total // 40), soft
 
@@ -84,6 +99,7 @@ def test_fuzz_nonconvex_campaign(ctx):
     for seed, count, n_lo, n_hi, shift in plan:
         b, s = _campaign(ctx, seed, count, n_lo, n_hi, dict(nonconvex=1, q_shift=shift))
         bad += b; soft += s; total += count
+    _report(ctx, "N nonconvex", total, bad, soft)
     assert not bad, bad
     # indefinite LDL' without pivoting: more counts are decided by rounding than in the convex campaigns (round 4: 37 of 610, of which
     # seven are EMPTY random Hessians on which the reference's LOBPCG divides by the norm of a zero residual, nonconvex.c:75-77)
@@ -97,6 +113,7 @@ def test_fuzz_dual_termination_campaign(ctx):
     for seed, count, n_lo, n_hi in plan:
         b, s = _campaign(ctx, seed, count, n_lo, n_hi, dict(enable_dual_termination=1))
         bad += b; soft += s; total += count
+    _report(ctx, "D dual termination", total, bad, soft)
     assert not bad, bad
     assert len(soft) <= max(1, total // 50), soft
 
@@ -126,15 +143,35 @@ def test_fuzz_sparse_factor_campaign(ctx):
                     okd, why, rounding = judge_case(rd, p, st, warm, 1e-8, ctx)
                     ctx.set_option("sparse_factor", 1)
                     if okd and rounding:
-                        soft.append((seed, it, r["status"], r["iter"], why))
+                        soft.append((seed, it, r["status"], r["iter"], why, rounding))
                     else:
                         bad.append((seed, it, meta, r["status"], r["iter"], r["dx"], r["dy"]))
                 total += 1
     finally:
         ctx.set_option("sparse_factor", -1)
         ctx.set_option("sparse_ordering", -1)
+    _report(ctx, "S sparse factor", total, bad, soft)
     assert not bad, bad
     assert len(soft) <= max(1, total // 50), soft
+
+
+def test_fuzz_linear_programmes_campaign(ctx):
+    """Campaign L (round 6; round 5 ran it by hand as campaigns 701 / 702, profiles/r05/fuzz_final/lp_*): Q zeroed, so H = A' Sigma A + I / gamma has
+    pivots down to 1 / gamma_max = 1e-7 -- and is exactly singular where the drawn settings switch the proximal term off and fewer rows are
+    active than there are variables.  These are the problems on which (i) the prefix-tree pivots of round 5 lost eight digits (now: the
+    per-column guard of qp_rank_pivots, and the running pivot throughout for QPs flagged at setup), (ii) a pivot crossing zero inside a sweep
+    gave a non-finite Newton direction and MAX_ITER with a NaN iterate where the oracle converges (case 701 / 114; now: the step is taken
+    again with a fresh factorisation, engine and oracle alike).  Rule: judge_case -- and a non-finite engine iterate passes only in the bucket
+    "singular" (a reference build of the oracle -- plain, FMA or -Ofast -- ends non-finite with the same status), never as rounding."""
+    plan = [(702, 8, 2, 40)] if ctx.kind == "emu" else [(701, 200, 70, 400), (702, 300, 2, 70)]
+    bad, soft, total = [], [], 0
+    for seed, count, n_lo, n_hi in plan:
+        b, s = _campaign(ctx, seed, count, n_lo, n_hi, dict(lp=1, factorization_method=1) if seed == 701 else dict(lp=1))
+        bad += b; soft += s; total += count
+    by = _report(ctx, "L linear programmes", total, bad, soft)
+    assert not bad, bad
+    # LPs are degenerate: a fifth of them change their count with the compiler's flags (round 5: 12 + 44 of 500 outside the singular bucket)
+    assert by.get("rounding", 0) + by.get("engine-form", 0) <= max(2, total // 5), by
 
 
 def test_sigma_grown_by_one_ulp(ctx):

@@ -789,23 +789,42 @@ def test_linesearch_sort_buffer_in_hbm_with_lds_tiles(ctx):
         assert np.array_equal(out[0][0], out[hbm][0]) and np.array_equal(out[0][1], out[hbm][1]), hbm
 
 
+def _with_Q(p, kind):
+    """the problem with another Hessian: "lp" Q = 0; "tiny" Q = 1e-10 I; "rank1" Q = 1e-10 v v' (positive diagonal, rank one)"""
+    n = p.n
+    if kind == "lp":
+        Qd = np.zeros((n, n))
+    elif kind == "tiny":
+        Qd = 1e-10 * np.eye(n)
+    else:
+        v = 1.0 + np.arange(n) / n
+        Qd = 1e-10 * np.outer(v, v)
+    Ql = sp.csc_matrix(np.tril(Qd)) if kind != "lp" else sp.csc_matrix((n, n))
+    Ql.sort_indices()
+    return type(p)(p.n, p.m, Ql.indptr.astype(np.int64), Ql.indices.astype(np.int64), Ql.data.astype(np.float64), p.Ap, p.Ai, p.Ax, p.q, p.bmin, p.bmax)
+
+
 def test_downdate_into_a_numerically_singular_matrix_is_backward_stable(ctx):
-    """Round 5, fuzz LP case 701 / 128 boiled down: H = A' Sigma A + I / gamma with gamma = 1e7 and sigma = 1e3; 86 of the 90 active rows
+    """Round 5, fuzz LP case 701 / 128 boiled down: H = Q + A' Sigma A + I / gamma with gamma = 1e7 and sigma = 1e3; 86 of the 90 active rows
     leave at once (six sweeps of 16 ranks), lambda_min goes from 150 to 1e-7.  With the sweep's pivots taken as d_0 + sum(p) the factor
-    that comes out has a backward error of 2e-8; carried as the running pivot d_r = d_{r-1} + p_r (qp_rank_pivots_seq, chosen by the
-    library for QPs whose Q has no positive diagonal) it is backward stable -- both forms run here, the second must stay below 1e-13."""
+    that comes out has a backward error of 2e-8; carried as the running pivot d_r = d_{r-1} + p_r it is backward stable.  Round 6: in the
+    DEFAULT configuration the library sums a column as running pivots whenever a pivot shrinks by 2^8 or more inside a sweep (the per-column
+    guard of qp_rank_pivots), whatever Q looks like: an LP (also flagged at setup: every column sequential), Q = 1e-10 I and a rank-one
+    positive semidefinite Q with a positive diagonal (the two the structural hint of round 5 missed) must all stay below 1e-13; the
+    unguarded tree (sequential_rank_sums = 0, an A/B option) is run beside them and loses eight digits."""
     n, m = 40, 120
     st = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0, scaling=0, gamma_init=1e7, gamma_max=1e7, sigma_init=1e3)
-    err = {}
+    err, nseq = {}, {}
     try:
-        for mode in (0, -1):
+        for mode, kind in ((0, "tiny"), (-1, "lp"), (-1, "tiny"), (-1, "rank1"), (1, "tiny")):
             ctx.set_option("sequential_rank_sums", mode)
-            p = random_qp(n, m, seed=9100, density_A=0.08, density_M=0.05)
-            p.Qx[:] = 0.0                                     # an LP: the engine's setup flags it (seq_hint)
+            p = _with_Q(random_qp(n, m, seed=9100, density_A=0.08, density_M=0.05), kind)
             bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
             bt.begin_solve()
             bt.iterate(2)                                     # sigma and A' sqrt(Sigma) are set up by the first iterations
             A = sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n)).toarray()
+            Ql = sp.csc_matrix((p.Qx, p.Qi, p.Qp), shape=(p.n, p.n)).toarray()
+            Qd = Ql + np.tril(Ql, -1).T
             act = np.zeros(m, dtype=np.int64); act[:90] = 1
             bt.set_ivec("active", act)
             bt.op("ldlcholQAtsigmaA")
@@ -816,12 +835,15 @@ def test_downdate_into_a_numerically_singular_matrix_is_backward_stable(ctx):
             L = np.tril(L, -1) + np.eye(n)
             keep = act.copy(); keep[leave] = 0
             sig, gam = bt.vec("sigma", 0)[:m], float(bt.stats(0).gamma)
-            H = (A[keep == 1].T * sig[keep == 1]) @ A[keep == 1] + np.eye(n) / gam
-            H0 = (A[act == 1].T * sig[act == 1]) @ A[act == 1] + np.eye(n) / gam
+            H = Qd + (A[keep == 1].T * sig[keep == 1]) @ A[keep == 1] + np.eye(n) / gam
+            H0 = Qd + (A[act == 1].T * sig[act == 1]) @ A[act == 1] + np.eye(n) / gam
             assert np.min(np.linalg.eigvalsh(H)) < 1e-8 * np.min(np.linalg.eigvalsh(H0))
-            err[mode] = np.max(np.abs(L @ np.diag(D) @ L.T - H)) / np.max(np.abs(H0))
+            err[mode, kind] = np.max(np.abs(L @ np.diag(D) @ L.T - H)) / np.max(np.abs(H0))
+            nseq[mode, kind] = int(bt.stats(0).n_seq_columns)
             bt.close()
     finally:
         ctx.set_option("sequential_rank_sums", -1)
-    assert err[-1] <= 1e-13, err
-    assert err[0] >= 1e-10, err          # (what the prefix-tree form loses on this matrix: the reason for the option)
+    for key in ((-1, "lp"), (-1, "tiny"), (-1, "rank1"), (1, "tiny")):
+        assert err[key] <= 1e-13, err
+    assert err[0, "tiny"] >= 1e-10, err          # (what the unguarded prefix-tree form loses on this matrix: the reason for the guard)
+    assert nseq[-1, "tiny"] > 0 and nseq[-1, "rank1"] > 0 and nseq[0, "tiny"] == 0 and nseq[1, "tiny"] == 0, nseq   # the guard is what did it

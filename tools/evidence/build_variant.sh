@@ -1,7 +1,7 @@
 #!/bin/bash
 # an experimental build of the HIP library next to the shipped one:
 #   tools/evidence/build_variant.sh [--patch file.patch] [--ipra] <name> "<extra -D flags>"
-# -> qpalm_amd/lib/libqpalm_gfx950_<name>.so (git-ignored, travels to the GPU box; run with bench.py --lib or tools/scratch/ab_multi.sh)
+# -> qpalm_amd/lib/libqpalm_gfx950_<name>.so (git-ignored, travels to the GPU box; run with bench.py --lib or tools/evidence/gpu_ab.sh)
 # --patch: the sources are copied to a scratch directory and the patch (tools/variants/*.patch) is applied there.
 set -e
 cd "$(dirname "$0")/../.."

@@ -35,7 +35,9 @@ if sparse:
     force.update(dict(factorization_method=1, enable_dual_termination=0))
 worst_dy_ratio = 0.0   # largest dy / derived bound among the cases that needed more than 1e-8 on y
 bad = 0    # fails the rule (or an exception)
-soft = 0   # passes as a rounding-decided case
+soft = 0   # passes, but not as an outright match: by bucket in `by` (rounding / engine-form / singular: tests/fuzz_cases.py, judge_case)
+by = {}
+guards = [0, 0]   # Newton steps redone with a fresh factorisation (engine, oracle)
 t0 = time.time()
 for it, p, st, warm, meta in cases(seed, N, NLO, NHI, force or None):
     try:
@@ -43,13 +45,16 @@ for it, p, st, warm, meta in cases(seed, N, NLO, NHI, force or None):
         ok, why, rounding = judge_case(r, p, st, warm, 1e-8, ctx if not sparse else None)
         if r.get("ytol_used", 0) > 1e-8 and r["dy"] > 1e-8:
             worst_dy_ratio = max(worst_dy_ratio, r["dy"] / r["ytol_used"])
+        guards[0] += r["guard"][0]; guards[1] += r["guard"][1]
         if not ok or rounding:
             bad += 0 if ok else 1
             soft += 1 if ok else 0
-            print("FAIL" if not ok else "ROUNDING-DECIDED", "seed", seed, "case", it, meta, {k: st[k] for k in ("factorization_method", "sigma_init", "scaling", "proximal")},
+            if ok:
+                by[rounding if isinstance(rounding, str) else "rounding"] = by.get(rounding if isinstance(rounding, str) else "rounding", 0) + 1
+            print("FAIL" if not ok else {"rounding": "ROUNDING-DECIDED", "engine-form": "ENGINE-FORM", "singular": "SINGULAR"}.get(rounding, "ROUNDING-DECIDED"), "seed", seed, "case", it, meta, {k: st[k] for k in ("factorization_method", "sigma_init", "scaling", "proximal")},
                   "status", r["status"], "iter", r["iter"], "x", r["dx"], "y", r["dy"], "|", why)
             sys.stdout.flush()
     except Exception as e:
         bad += 1
         print("EXC", it, meta, st, repr(e)[:300])
-print("done seed", seed, "cases", N, "n", (NLO, NHI), "forced", force, "FAIL", bad, "rounding-decided", soft, "largest dy / derived y bound", round(worst_dy_ratio, 3), "time", round(time.time() - t0, 1))
+print("done seed", seed, "cases", N, "n", (NLO, NHI), "forced", force, "FAIL", bad, "accepted-not-exact", soft, by, "newton steps redone (engine, oracle)", guards, "largest dy / derived y bound", round(worst_dy_ratio, 3), "time", round(time.time() - t0, 1))
