@@ -188,6 +188,23 @@ def phase_bytes(model, st, iters):
     }
 
 
+def pmc_traffic(name, key, lib=None, explicit=None):
+    """HBM bytes per launch from the committed PMC summary `profiles/r*/final/<name>` (tools/evidence/round_artifacts.sh: separate rocprofv3 --pmc
+    passes, FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md), newest round first -- quoted ONLY when the hashes of the kernel sources and of
+    the loaded library recorded in the summary equal this run's and the workload key (batch, n, m) matches; else (None, None)."""
+    import glob
+    cands = [explicit] if explicit else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final", name)), reverse=True)
+    for cand in cands:
+        try:
+            with open(cand) as f:
+                pj = json.load(f)
+            if pj["source_sha256"] == source_sha256() and pj.get("lib_sha256") == lib_sha256(lib) and (pj["batch"], pj["n"], pj["m"]) == tuple(key):
+                return float(pj["traffic_bytes_per_launch"]), os.path.relpath(cand, ROOT)
+        except Exception:   # noqa: BLE001
+            pass
+    return None, None
+
+
 def cpu_model_string():
     try:
         with open("/proc/cpuinfo") as f:
@@ -359,8 +376,26 @@ def mpc160_line(ctx, B, kkt, steps, warmup=1):
     it = np.array([int(i.iter) for i in infos])
     worst = kkt_spot_check(probs, sol[0], sol[1], sorted({0, B // 2, B - 1}), bmin_all, bmax_all)
     mean = lambda f: float(np.mean([f(s) for s in stats]))
+    # byte model of config 3: the same per-unit bytes as the headline at this size -- per QP a
+    # factorisation writes nnz(L) 8 = 103 KB (Schur: 160 rows; KKT: the (n+m)-row panel) and reads Q, A once, a Newton solve streams L twice
+    # (minus the forward halves fused into a sweep), a sweep reads and writes the entries it touches (device counter), SpMVs and vectors as 8d
+    # -- counted from the device-side work counters of the LAST warm-started step, over that step's kernel time (HIP events on the launch's stream)
+    tot = {"solve": 0, "spmv_vectors": 0, "factor": 0, "update": 0, "solve_fused_away": 0}
+    for b in range(B):
+        pb = phase_bytes(byte_model(n, m, int(probs[b].Ap[-1]), int(probs[b].Qp[-1]), (n + m) if kkt else None), stats[b], int(it[b]))
+        for k in tot:
+            tot[k] += pb[k]
+    fused_away = tot.pop("solve_fused_away")
+    alg = sum(tot.values()) - fused_away
+    traffic, traffic_src = pmc_traffic("mpc160_kkt_pmc_traffic.json" if kkt else "mpc160_pmc_traffic.json", (B, n, m))
+    roof = {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP), one warm-started step", "achieved": alg / (kms[-1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (kms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms[-1], "algorithmic_bytes_per_launch": alg, "fused_away_bytes_per_launch": fused_away,
+            "bytes_per_qp": {k: v / B for k, v in tot.items()}, "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+            "note": "latency-bound at this size: every phase of a 160-variable QP is a chain of dependent round trips; the fraction says how far "
+                    "the bytes it must move are from what the chip could stream, the traffic ratio how many bytes it moves beyond them"}
     out = {"workload": "mpc-160 (n=%d m=%d), %d QPs, %d warm-started steps, %s" % (n, m, B, steps, "KKT panel, row add / delete" if kkt else "Schur panel, rank updates"),
-           "value": B * steps / dt, "unit": "QP/s", "ms_per_step": 1e3 * dt / steps, "kernel_ms_per_step": float(np.mean(kms)),
+           "value": B * steps / dt, "unit": "QP/s", "ms_per_step": 1e3 * dt / steps, "kernel_ms_per_step": float(np.mean(kms)), "roofline": roof,
            "all_solved": bool(np.all(st == 1)), "kkt_spot_check_worst_rel": worst, "iter_mean": float(it.mean()),
            "per_qp_mean": {k: mean(lambda s, k=k: getattr(s, k)) for k in ("n_refactor", "n_factor_Q", "n_sweeps", "n_rank1", "n_solve")},
            "ms_per_qp_in_kernel": {"total": mean(lambda s: s.ms_total), "factor": mean(lambda s: s.ms_factor), "update": mean(lambda s: s.ms_update),
@@ -588,18 +623,19 @@ def worker(args):
                 "solve": mean(lambda s: s.ms_solve), "linesearch": mean(lambda s: s.ms_linesearch), "residuals": mean(lambda s: s.ms_dbg[12])}
     phase_ms["dbg"] = [mean(lambda s, k=k: s.ms_dbg[k]) for k in range(16)]
     conc, wg_threads, wg_lds = bt.launch_shape()
-    # aggregate GB/s of a phase = bytes of all QPs / (time the phase occupies one of `conc` concurrent workgroups)
+    # NORMALISED GB/s of a phase = bytes of all QPs / (time the phase occupies one of `conc` concurrent workgroups): what the chip would move if
+    # every resident workgroup were in that phase at once -- a normalisation (it can exceed what the memory system delivers), not a measurement
     def phase_gbs(nbytes, ms_per_qp):
         return nbytes / (max(ms_per_qp, 1e-9) * 1e-3 * B / conc) / 1e9
     phases = {
-        "solve": {"bytes": tot["solve"] - fused_away, "ms_per_qp": phase_ms["solve"], "GBps": phase_gbs(tot["solve"] - fused_away, phase_ms["solve"]),
+        "solve": {"bytes": tot["solve"] - fused_away, "ms_per_qp": phase_ms["solve"], "GBps_normalised": phase_gbs(tot["solve"] - fused_away, phase_ms["solve"]),
                   "fused_away_bytes": fused_away},
-        "update": {"bytes": tot["update"], "ms_per_qp": phase_ms["update"], "GBps": phase_gbs(tot["update"], phase_ms["update"])},
-        "factor": {"bytes": tot["factor"], "ms_per_qp": phase_ms["factor"], "GBps": phase_gbs(tot["factor"], phase_ms["factor"]),
+        "update": {"bytes": tot["update"], "ms_per_qp": phase_ms["update"], "GBps_normalised": phase_gbs(tot["update"], phase_ms["update"])},
+        "factor": {"bytes": tot["factor"], "ms_per_qp": phase_ms["factor"], "GBps_normalised": phase_gbs(tot["factor"], phase_ms["factor"]),
                    "flop": float(sum((int(s.n_refactor) + int(s.n_factor_Q)) for s in stats)) * n ** 3 / 3.0,
                    "reread_bytes": float(sum(int(s.factor_reread_entries) for s in stats)) * 8},
         "spmv_vectors": {"bytes": tot["spmv_vectors"], "ms_per_qp": phase_ms["linesearch"] + phase_ms["residuals"],
-                         "GBps": phase_gbs(tot["spmv_vectors"], phase_ms["linesearch"] + phase_ms["residuals"])},
+                         "GBps_normalised": phase_gbs(tot["spmv_vectors"], phase_ms["linesearch"] + phase_ms["residuals"])},
     }
     phases["factor"]["TFLOPs"] = phases["factor"]["flop"] / (max(phase_ms["factor"], 1e-9) * 1e-3 * B / conc) / 1e12
     rc = 0
@@ -610,25 +646,13 @@ def worker(args):
         nsl = conc
         ms_ldl = bt.ldlsolve_all(reps=4)                    # stand-alone LDL' solve kernel ("HBM GB/s on LDL")
         ldl_bytes = nsl * model0["b_solve"]
-        traffic = None
-        traffic_src = None
         # the PMC summary of the SAME build (tools/evidence/round_artifacts.sh writes it, separate rocprofv3 --pmc passes): --traffic-json names
         # one; without the flag the committed summaries under profiles/ are tried, newest round first.  Quoted only when the hashes of the
         # kernel sources and of the loaded library recorded in the summary equal this run's (else roofline.traffic stays null).
-        import glob
-        cands = [args.traffic_json] if args.traffic_json else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final", "k_solve_pmc_traffic.json")), reverse=True)
-        for cand in (cands if world == 1 else []):
-            try:
-                with open(cand) as f:
-                    pj = json.load(f)
-                if pj["source_sha256"] == source_sha256() and pj.get("lib_sha256") == lib_sha256(args.lib) and (pj["batch"], pj["n"], pj["m"]) == (B, n, m):
-                    traffic = float(pj["traffic_bytes_per_launch"])
-                    traffic_src = os.path.relpath(cand, ROOT)
-                    break
-            except Exception:
-                traffic = None
+        traffic, traffic_src = pmc_traffic("k_solve_pmc_traffic.json", (B, n, m), args.lib, args.traffic_json) if world == 1 else (None, None)
         out = {
-            "metric": "QP solves/sec (batched %s)" % ("random n=%d,m=%d" % (n, m) if args.workload == "random-1000" else "MPC n=%d,m=%d, warm-started sequence" % (n, m)),
+            "metric": "QP solves/sec (batched %s); `value` = solve only, batch resident in HBM -- with qpalm_setup in the clock as the reference's run_time has it: `value_setup_plus_solve`"
+                      % ("random n=%d,m=%d" % (n, m) if args.workload == "random-1000" else "MPC n=%d,m=%d, warm-started sequence" % (n, m)),
             "value": world * B * args.steps / elapsed, "unit": "QP/s",
             # the reference's info.run_time = setup_time + solve_time (src/qpalm.c:493-495,721-723): the same rate with qpalm_setup's work
             # of this batch added to one step (set_problem: host-side copies / format conversion, single-threaded; batch_setup: packing,

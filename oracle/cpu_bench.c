@@ -61,6 +61,7 @@ static void *worker(void *arg) {
     const double t1 = now_s();
     if (!w) continue;
     if (g_sparse) oq_set_scalar(w, "sparse_mode", 1);
+    else oq_set_scalar(w, "updown_block", 8); /* up to eight ranks per pass over L, as cholmod_updown does (bit-identical to the rank-1 sweeps the parity tests use) */
     oq_solve(w);
     const double t2 = now_s();
     const oq_info *info = oq_get_info(w);

@@ -84,6 +84,8 @@ struct oq_workspace {
   oq_float lobpcg_lambda;
   oq_float *Hbuf; /* scratch n*n for forming Q + A'SA */
   oq_float *wbuf; /* scratch n for rank-1 vectors */
+  int updown_block; /* > 1: updown_columns applies up to OQ_UPDOWN_BLOCK ranks per pass over L (bit-identical; cpu_baseline only) */
+  oq_float *wblock; /* its OQ_UPDOWN_BLOCK x n vectors */
   /* sparse-storage mode of the Schur factor (round 5): the SAME factorisation and solves on a compressed-column L -- what CHOLMOD's
    * simplicial analyze / factorize / solve do -- for problems whose n^2 panel is out of reach (n = 20 000 .. 100 000).  Every entry
    * receives the operations of the dense routines above in the same order (structural zeros are skipped, and a skipped operation adds
@@ -104,11 +106,10 @@ struct oq_workspace {
   oq_int n_refactor, n_factor_Q, n_updown_calls, n_rank1, n_solve, n_sigma_updates, n_boost_gamma;
   oq_int last_fact;
   /* NOT in the reference (stated deviation, restated by the engine: qpalm_iter.h, dev_solve): a Newton step whose direction comes out of an
-   * UPDATED factor and is not finite (eta or beta of the line search is not finite: a pivot went through zero inside an update), or whose
-   * update left a pivot that is not > 0 in a convex QP (the matrix is positive definite: the factor has broken down), is taken again with
-   * a fresh factorisation.  The reference iterates on (solver_interface.c:357-368 looks at c->status only when !DLONG); on such a case
+   * UPDATED factor and is not finite (eta or beta of the line search is not finite: a pivot went through zero inside an update) is taken again
+   * with a fresh factorisation.  The reference iterates on (solver_interface.c:357-368 looks at c->status only when !DLONG); on such a case
    * its iterates are NaN to max_iter.  guard = 0 (oq_set_scalar "newton_guard") restates the reference without it. */
-  int guard, pivot_bad;
+  int guard;
   oq_int n_guard_refactor;
   oq_trace *trace;
 };
@@ -672,6 +673,7 @@ oq_workspace *oq_setup(oq_int n_, oq_int m_, const oq_int *Qp, const oq_int *Qi,
 }
 
 void oq_cleanup(oq_workspace *w) {
+  if (w) free(w->wblock);
   if (!w) return;
   sp_free(&w->A); sp_free(&w->Q); if (w->At_sqrt_sigma.p) sp_free(&w->At_sqrt_sigma);
   oq_float **fv[] = {&w->q, &w->bmin, &w->bmax, &w->x, &w->y, &w->Ax, &w->Qx, &w->Aty, &w->x_prev, &w->x0,
@@ -759,7 +761,6 @@ static void initialize_sigma(oq_workspace *w) { /* iteration.c:50-84 */
   sp_scale_col(&w->At_sqrt_sigma, w->At_scale);
 }
 
-static int factor_has_bad_pivot(const oq_workspace *w);
 void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
   size_t m = (size_t)w->m;
   const oq_settings *st = &w->settings;
@@ -811,7 +812,6 @@ void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
     /* nothing */
   } else {
     oq_ldlupdate_sigma_changed(w);
-    if (factor_has_bad_pivot(w)) w->reset_newton = 1; /* NOT in the reference (oq_workspace::guard): the factor broke down in this update */
   }
 }
 
@@ -1100,12 +1100,73 @@ void oq_ldlcholQAtsigmaA(oq_workspace *w) { /* solver_interface.c:372-405 */
   w->LD.valid = 1;
 }
 
+/* The same update for up to OQ_UPDOWN_BLOCK ranks in ONE pass over L, as cholmod_updown carries up to eight ranks per pass: column by column, rank
+ * after rank inside a column.  Every entry of L, D and of the vectors receives exactly the operations of the rank-1 routine above in the
+ * same order (rank r meets column j after ranks < r have met it and after it has itself met the columns < j), so the result is
+ * BIT-IDENTICAL to applying the ranks one after the other -- tests/test_oracle_golden.py checks that -- while L is streamed once per
+ * block instead of once per rank.  Used by bench.py's cpu_baseline leg (oq_set_scalar "updown_block"); the parity tests keep the scalar form. */
+#define OQ_UPDOWN_BLOCK 8
+static void dense_ldl_rankk(oq_int n, oq_float *L, oq_int ld, oq_float *D, oq_float *W, oq_int k, int update) {
+  oq_float alpha[OQ_UPDOWN_BLOCK], wj[OQ_UPDOWN_BLOCK], gam[OQ_UPDOWN_BLOCK];
+  oq_int j0 = n;
+  for (oq_int r = 0; r < k; r++) {
+    alpha[r] = 1.0;
+    oq_int f = 0;
+    while (f < n && W[r * n + f] == 0.0) f++;
+    if (f < j0) j0 = f;
+  }
+  for (oq_int j = j0; j < n; j++) {
+    oq_float dj = D[j];
+    for (oq_int r = 0; r < k; r++) {
+      oq_float a;
+      wj[r] = W[r * n + j];
+      if (wj[r] == 0.0 && alpha[r] == 1.0) { gam[r] = 0.0; continue; } /* above the rank's first nonzero: the rank-1 routine has not started yet (exact no-op) */
+      if (update) { a = alpha[r] + (wj[r] * wj[r]) / dj; dj *= a; gam[r] = -wj[r] / dj; }
+      else        { a = alpha[r] - (wj[r] * wj[r]) / dj; dj *= a; gam[r] =  wj[r] / dj; }
+      dj /= alpha[r];
+      alpha[r] = a;
+    }
+    D[j] = dj;
+    oq_float *Lj = L + j * ld;
+    /* kp streams + the column, independent across i: the compiler vectorises over i (same operations per entry, same order).  k is padded up to
+     * 1, 2, 4 or 8 streams with zero vectors (w_j = 0, gamma = 0: exact no-ops on finite entries). */
+#define OQ_RK_STEP(r) t = wp[r][i] - wj[r] * l; wp[r][i] = t; l -= gam[r] * t;
+#define OQ_RK_LOOP(BODY) { _Pragma("GCC ivdep") for (oq_int i = j + 1; i < n; i++) { oq_float l = l_[i], t; BODY l_[i] = l; } }
+    {
+      oq_float *restrict l_ = Lj;
+      oq_float *restrict wp[OQ_UPDOWN_BLOCK];
+      for (int r = 0; r < OQ_UPDOWN_BLOCK; r++) wp[r] = W + (size_t)r * (size_t)n; /* (rows k .. kp-1 of W are zero: dense_ldl_rankk's caller clears kp rows) */
+      for (oq_int r = k; r < OQ_UPDOWN_BLOCK; r++) { wj[r] = 0.0; gam[r] = 0.0; }
+      if (k == 1) OQ_RK_LOOP(OQ_RK_STEP(0))
+      else if (k == 2) OQ_RK_LOOP(OQ_RK_STEP(0) OQ_RK_STEP(1))
+      else if (k <= 4) OQ_RK_LOOP(OQ_RK_STEP(0) OQ_RK_STEP(1) OQ_RK_STEP(2) OQ_RK_STEP(3))
+      else OQ_RK_LOOP(OQ_RK_STEP(0) OQ_RK_STEP(1) OQ_RK_STEP(2) OQ_RK_STEP(3) OQ_RK_STEP(4) OQ_RK_STEP(5) OQ_RK_STEP(6) OQ_RK_STEP(7))
+    }
+#undef OQ_RK_STEP
+#undef OQ_RK_LOOP
+  }
+}
 static void updown_columns(oq_workspace *w, const oq_int *cols, oq_int ncols, int update) {
   /* submatrix(At_sqrt_sigma, :, cols) then updown(update, C, L) (solver_interface.c:415-421,433-439) */
   oq_int n = w->n;
   if (w->sparse_mode) { w->n_updown_calls++; for (oq_int c = 0; c < ncols; c++) { sparse_rank1(w, cols[c], update); w->n_rank1++; } return; }
   const oq_sparse *F = &w->At_sqrt_sigma;
   w->n_updown_calls++;
+  if (w->updown_block > 1) {
+    if (!w->wblock) w->wblock = (oq_float *)malloc((size_t)OQ_UPDOWN_BLOCK * (size_t)(n ? n : 1) * sizeof(oq_float));
+    for (oq_int c0 = 0; c0 < ncols; c0 += OQ_UPDOWN_BLOCK) {
+      const oq_int k = (ncols - c0 < OQ_UPDOWN_BLOCK) ? (ncols - c0) : OQ_UPDOWN_BLOCK;
+      const oq_int kp = (k <= 2) ? k : ((k <= 4) ? 4 : OQ_UPDOWN_BLOCK); /* streams the kernel runs (zero vectors beyond k) */
+      memset(w->wblock, 0, (size_t)kp * (size_t)n * sizeof(oq_float));
+      for (oq_int r = 0; r < k; r++) {
+        const oq_int t = cols[c0 + r];
+        for (oq_int e = F->p[t]; e < F->p[t + 1]; e++) w->wblock[r * n + F->i[e]] = F->x[e];
+      }
+      dense_ldl_rankk(n, w->LD.L, n, w->LD.D, w->wblock, k, update);
+      w->n_rank1 += k;
+    }
+    return;
+  }
   for (oq_int c = 0; c < ncols; c++) {
     oq_int t = cols[c];
     memset(w->wbuf, 0, (size_t)n * sizeof(oq_float));
@@ -1319,15 +1380,8 @@ static void kkt_newton_direction(oq_workspace *w) { /* newton.c:22-95 */
   kkt_solve_refine(w);
 }
 
-/* the guard's second trigger (see oq_workspace::guard): after the updates of a step, a pivot of a convex QP's Schur factor that is not > 0 */
-static int factor_has_bad_pivot(const oq_workspace *w) {
-  if (!w->guard || w->settings.nonconvex || w->sparse_mode || w->kkt_mode) return 0;
-  for (oq_int j = 0; j < w->n; j++) if (!(w->LD.D[j] > 0)) return 1;
-  return 0;
-}
 void oq_newton_set_direction(oq_workspace *w) { /* newton.c:17-120 */
   const oq_settings *st = &w->settings;
-  w->pivot_bad = 0;
   oq_set_active_constraints(w);
   oq_set_entering_leaving_constraints(w);
   if (w->kkt_mode) {
@@ -1345,7 +1399,6 @@ void oq_newton_set_direction(oq_workspace *w) { /* newton.c:17-120 */
     w->last_fact = 0;
     if (w->nb_enter) { oq_ldlupdate_entering_constraints(w); w->last_fact = 2; }
     if (w->nb_leave) { oq_ldldowndate_leaving_constraints(w); w->last_fact = 2; }
-    if (w->last_fact == 2) w->pivot_bad = factor_has_bad_pivot(w);
   } else {
     oq_ldlchol(&w->Q, w); w->n_factor_Q++; w->last_fact = 3; /* B7 */
   }
@@ -1420,13 +1473,12 @@ void oq_update_primal_iterate(oq_workspace *w) { /* iteration.c:213-229 */
   size_t n = (size_t)w->n, m = (size_t)w->m;
   oq_newton_set_direction(w);
   w->tau = oq_exact_linesearch(w);
-  if (w->guard && (w->last_fact == 0 || w->last_fact == 2) && (!isfinite(w->eta) || !isfinite(w->beta) || w->pivot_bad)) {
+  if (w->guard && (w->last_fact == 0 || w->last_fact == 2) && (!isfinite(w->eta) || !isfinite(w->beta))) {
     /* NOT in the reference (oq_workspace::guard): the step is taken again with a fresh factorisation; the active sets and the
      * enter / leave counts of the step stay as they are (they are read again by the loop, B4) */
     w->n_guard_refactor++;
     if (w->kkt_mode) { kkt_form_and_factor(w); w->n_refactor++; w->last_fact = 1; kkt_solve_refine(w); }
     else { oq_ldlcholQAtsigmaA(w); w->n_refactor++; w->last_fact = 1; oq_ldlsolveLD_neg_dphi(w); }
-    w->pivot_bad = 0;
     w->tau = oq_exact_linesearch(w);
   }
   vec_cp(w->x, w->x_prev, n);
@@ -1843,6 +1895,7 @@ void oq_set_scalar(oq_workspace *w, const char *name, oq_float v) {
   else if (!strcmp(name, "tau")) w->tau = v;
   else if (!strcmp(name, "proximal")) w->settings.proximal = (oq_int)v;
   else if (!strcmp(name, "reset_newton")) w->reset_newton = (int)v;
+  else if (!strcmp(name, "updown_block")) w->updown_block = (int)v; /* > 1: the blocked multi-rank form of updown_columns (same bits, L streamed once per eight ranks) */
   else if (!strcmp(name, "newton_guard")) w->guard = (v != 0); /* 0: the reference's behaviour, no guard against a non-finite Newton direction (oq_workspace::guard) */
   else if (!strcmp(name, "sparse_mode")) w->sparse_mode = (v != 0 && !w->kkt_mode && !w->settings.enable_dual_termination) ? (int)v : 0; /* before the first solve; 1 = path
                                                          updates where they pay (the engine's rule), 2 = every change refactorises (what pins the mode against the dense one) */

@@ -1705,7 +1705,6 @@ QP_NI_UPDOWN void dense_updown(const int *Atp_, const int *Ati_, const double *A
           QP_SCHED_BARRIER();
         }
         if (QP_PANEL_TIMING == 1 && lane == 0) tdbg[9] += QP_CLOCK() - tp1;
-        if (lane < jb && !(dreg > 0.0)) S.pivot_bad = 1; /* (rare) a pivot that is not > 0: the caller knows whether that is a breakdown (convex QP) */
         const long long tp2 = QP_CLOCK();
         if (fuse) { /* the diagonal block is final: y_J = L_JJ^{-1} (b_J - contributions of the earlier blocks) */
           double v = accp;
@@ -1915,7 +1914,6 @@ QPNI void dense_updown_big(const int *Atp_, const int *Ati_, const double *Atss_
         double dreg = (lane < jb) ? U.dd[lane] : 1.0;
         updown_big_panel<K>(U, lane, jb, kk, sg, wrow, dreg, alpha, ialpha, QP_UNIFORM(S.seq_ranks));
         if (lane < jb) Dg[J + lane] = dreg;
-        if (lane < jb && !(dreg > 0.0)) S.pivot_bad = 1; /* (as in dense_updown) */
 #pragma unroll 1
         for (int c = 0; c < jb; c++)
           if (lane > c && lane < jb) L[(size_t)(J + c) * ld + (J + lane)] = U.Ld[lane][c];

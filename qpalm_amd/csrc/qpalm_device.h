@@ -177,7 +177,6 @@ struct QpShared {          /* small static LDS block */
   int    placement;        /* diagnostic code of the placement (QPGStats.placement) */
   int    panel_wave;       /* the wavefront that runs the serial chains of the update sweep (qp_place_panel_wave) */
   int    seq_ranks;        /* how the update sweeps sum the ranks' contributions to a pivot (QP_PIV_*, set by dev_updown from qp_pivot_mode) */
-  int    pivot_bad;        /* an update sweep of a CONVEX QP left a pivot that is not > 0 (the matrix is positive definite: the factor has broken down) */
   int    wave_rank[QP_NW]; /* the sweep's name for each hardware wavefront: 0 = panel wave (owner of the first rows), then the wavefronts that
                               sit on the SIMDs where the CU's panel waves run (they get the rows that retire first), then the rest */
 };

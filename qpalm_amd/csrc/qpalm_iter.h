@@ -259,7 +259,7 @@ QPN void dev_updown(const qpg_view &V, int b, int n, double *L, double *Dg, doub
   /* how the sweeps sum a column's pivots (qp_pivot_mode, qpalm_device.h): the running pivot of the reference throughout for QPs whose factor can get
    * near-singular (nonconvex: indefinite; an LP or a Q with an empty diagonal: pivots down to 1 / gamma), else the guarded prefix tree */
   __syncthreads();
-  if (threadIdx.x == 0) { S.seq_ranks = qp_pivot_mode(V, b); S.pivot_bad = 0; }
+  if (threadIdx.x == 0) S.seq_ranks = qp_pivot_mode(V, b);
   __syncthreads();
   if constexpr (RPT == 0) dense_updown_big<16>(Atp, Ati, Atss, n, V.ld, L, Dg, Wst, up, n_up, dn, n_dn, &S, lds, tdbg, pre_jmin);
   else if constexpr (QP_K32(RPT)) {
@@ -1040,10 +1040,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     QP_OPAQUE(a.b);
     if (la == 4) {
       dev_update_sigma_post(a, I, n_sig);
-      if (tid == 0) {
-        I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0;
-        if (!resume && !SPARSE && I.s.nc_flag == 0 && I.S.pivot_bad != 0) I.s.reset_newton = 1; /* the guard above: the factor broke down in this update */
-      }
+      if (tid == 0) { I.s.n_sweeps = (int)I.s.ticks_dbg[QPG_CNT_SWEEPS]; I.s.ticks_update += t1 - t0; }
     } else if (la == 5 || la == 6) dev_boost_gamma_apply(V, a, I, gersh_ub);
     if (kind == QP_KIND_NEWTON) {
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
@@ -1074,14 +1071,14 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       const long long t3 = QP_CLOCK();
       QP_OPAQUE(a.b);
       /* NOT in the reference (stated deviation, restated by the oracle: oq_update_primal_iterate): a direction out of an UPDATED factor that is
-       * not finite (eta = d'(Q + I/gamma)d or beta = d'df: a pivot went through zero inside an update sweep), or an update that left a pivot
-       * not > 0 in a convex QP (H is positive definite: the factor has broken down), is not stepped along: the pass is taken again with a fresh
-       * factorisation.  The reference iterates on NaN to max_iter there (solver_interface.c:357-368 looks at c->status only when !DLONG).
-       * Fuzz case 701 / 114 (LP, sigma up to 1e9 against 1 / gamma = 1e-7).  Free on healthy steps: two compares on scalars the line search has. */
+       * not finite (eta = d'(Q + I/gamma)d or beta = d'df is not: a pivot went through zero inside an update sweep) is not stepped along: the
+       * pass is taken again with a fresh factorisation.  The reference iterates on NaN to max_iter there (solver_interface.c:357-368 looks at
+       * c->status only when !DLONG).  Fuzz case 701 / 114 (LP, sigma up to 1e9 against 1 / gamma = 1e-7).  Free on healthy steps: two compares
+       * on scalars the line search has.  (A second trigger -- an update that leaves a pivot <= 0 in a convex QP -- was built in round 6 and taken
+       * out: on LPs whose H is singular by construction it fires at every step, 80 000 times in campaign 701, and moves healthy trajectories.) */
       if (action == 0 || action == 2) {
         const double ge = I.s.eta, gb = I.s.beta;
-        const bool bad = !(qabs(ge) <= 1.7976931348623157e308) || !(qabs(gb) <= 1.7976931348623157e308) ||
-                         (la == 2 && !resume && !V.kkt && !SPARSE && I.s.nc_flag == 0 && I.S.pivot_bad != 0);
+        const bool bad = !(qabs(ge) <= 1.7976931348623157e308) || !(qabs(gb) <= 1.7976931348623157e308);
         if (QP_UNIFORM((int)bad) != 0) {
           __syncthreads();
           if (tid == 0) { I.s.guard_redo = 1; I.s.n_guard_refactor++; I.s.ticks_linesearch += t3 - t2; }

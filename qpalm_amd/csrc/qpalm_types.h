@@ -142,6 +142,8 @@ typedef struct {
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */
   int32_t *queue; /* [64 + QPG_CU_KEYS]: [0] work-queue head; [64 + key] workgroups that have arrived on compute unit `key` in this launch */
+  int32_t *order; /* [B] the work queue hands out order[0], order[1], ...: the members by the kernel time of their PREVIOUS solve, longest first
+                     (k_queue_order; identity before the first solve), so that the last QPs of a launch are short ones.  NULL: index order */
 } qpg_view;
 
 #define QPG_RPT_SPARSE 8 /* template argument of k_solve / dev_solve that selects the sparse factor (the dense instances use 0, 1, 2, 4) */

@@ -305,3 +305,22 @@ def test_nonconvex_qp_golden(golden):
     assert o.status_val == 1
     lam = -e["lambda_min"]
     assert abs(o.scalar("gamma") - 1.0 / lam) <= e["gamma_rel_tol"] / lam and 1 / o.scalar("gamma") > lam
+
+
+def test_blocked_multi_rank_update_is_bit_identical_to_the_rank_one_sweeps():
+    """bench.py's cpu_baseline runs the oracle with `updown_block = 8` (up to eight ranks per pass over L, as cholmod_updown carries them:
+    oracle/qpalm_oracle.c, dense_ldl_rankk) so that the stated CPU figure is not that of a form the reference's library would not run.
+    Every entry receives the operations of the rank-1 routine in the same order: the solve must agree BIT FOR BIT with the scalar form the
+    parity tests use -- iterates, multipliers, counts -- on QPs with rank updates of more and of fewer than eight rows."""
+    from qpalm_amd.problems import random_qp
+    for seed, n, m in ((11, 60, 150), (12, 90, 260)):
+        p = random_qp(n, m, seed=seed, density_A=0.08, density_M=0.05)
+        res = []
+        for block in (0, 8):
+            o = ob.OracleQP(*p.args(), settings=ob.default_settings(eps_abs=1e-8, eps_rel=1e-8, verbose=0))
+            o.set_scalar("updown_block", block)
+            o.solve()
+            res.append((o.status_val, int(o.info.iter), o.counter("n_rank1"), o.counter("n_refactor"), o.x.copy(), o.y.copy()))
+            o.cleanup()
+        assert res[0][:4] == res[1][:4] and res[0][0] == 1 and res[0][2] > 20, (res[0][:4], res[1][:4])
+        assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])

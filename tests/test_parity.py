@@ -735,6 +735,30 @@ def test_work_queue_more_qps_than_slots(ctx):
         ctx.set_option("max_slots", 512)
 
 
+def test_work_queue_starts_the_longest_previous_solves_first(ctx):
+    """Round 6: a launch through the work queue hands the members out in descending order of the kernel time of their PREVIOUS solve
+    (k_queue_order: the tail of the launch is then made of short solves; identity before the first solve).  The order must be exactly that
+    permutation, and must not change any result: the second solve equals the first bit for bit, and both equal the oracle."""
+    ctx.set_option("max_slots", 2)
+    n, m = sizes(ctx, (24, 48), (100, 200))
+    probs = [random_qp(n, m, seed=520 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(7)]
+    try:
+        bt = _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0))
+        B = len(probs)
+        assert [int(bt.ivec("queue_order", k, 1)[0]) for k in range(B)] == list(range(B))     # no previous solve: index order
+        x1, y1 = [a.copy() for a in bt.solution()]
+        cost = [float(bt.stats(k).ms_total) for k in range(B)]
+        bt.warm_start(None, None)
+        bt.solve()
+        order = [int(bt.ivec("queue_order", k, 1)[0]) for k in range(B)]
+        assert order == sorted(range(B), key=lambda k: (-cost[k], k)), (order, cost)
+        x2, y2 = bt.solution()
+        assert np.array_equal(x1, x2) and np.array_equal(y1, y2)
+        bt.close()
+    finally:
+        ctx.set_option("max_slots", 512)
+
+
 def test_warm_started_mpc_sequence(ctx):
     """update_bounds + warm_start between solves (the MPC use of the reference,
     simulations/randomMPCsequential.m:158-177)."""
