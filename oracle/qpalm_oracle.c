@@ -109,7 +109,7 @@ struct oq_workspace {
    * UPDATED factor and is not finite (eta or beta of the line search is not finite: a pivot went through zero inside an update) is taken again
    * with a fresh factorisation.  The reference iterates on (solver_interface.c:357-368 looks at c->status only when !DLONG); on such a case
    * its iterates are NaN to max_iter.  guard = 0 (oq_set_scalar "newton_guard") restates the reference without it. */
-  int guard;
+  int guard, guard_spent;
   oq_int n_guard_refactor;
   oq_trace *trace;
 };
@@ -1473,13 +1473,14 @@ void oq_update_primal_iterate(oq_workspace *w) { /* iteration.c:213-229 */
   size_t n = (size_t)w->n, m = (size_t)w->m;
   oq_newton_set_direction(w);
   w->tau = oq_exact_linesearch(w);
-  if (w->guard && (w->last_fact == 0 || w->last_fact == 2) && (!isfinite(w->eta) || !isfinite(w->beta))) {
+  if (w->guard && !w->guard_spent && (w->last_fact == 0 || w->last_fact == 2) && (!isfinite(w->eta) || !isfinite(w->beta))) {
     /* NOT in the reference (oq_workspace::guard): the step is taken again with a fresh factorisation; the active sets and the
      * enter / leave counts of the step stay as they are (they are read again by the loop, B4) */
     w->n_guard_refactor++;
     if (w->kkt_mode) { kkt_form_and_factor(w); w->n_refactor++; w->last_fact = 1; kkt_solve_refine(w); }
     else { oq_ldlcholQAtsigmaA(w); w->n_refactor++; w->last_fact = 1; oq_ldlsolveLD_neg_dphi(w); }
     w->tau = oq_exact_linesearch(w);
+    if (!isfinite(w->eta) || !isfinite(w->beta)) w->guard_spent = 1; /* the fresh factorisation gives a non-finite direction too (a NaN right-hand side, a singular H): nothing to repair, the guard is off for the rest of this solve */
   }
   vec_cp(w->x, w->x_prev, n);
   vec_cp(w->dphi, w->dphi_prev, n);
@@ -1678,6 +1679,7 @@ void oq_solve(oq_workspace *w) {
   w->eps_abs_in = st->eps_abs_in;
   w->eps_rel_in = st->eps_rel_in;
   w->reset_newton = 1;
+  w->guard_spent = 0;
   w->gamma = st->gamma_init;
   w->gamma_maxed = (0 || st->nonconvex);
   ivec_set(w->active_old, 0, m);

@@ -703,7 +703,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       I.s.eps_k_abs = st.eps_abs_in; I.s.eps_k_rel = st.eps_rel_in;
       I.s.in_solve = 1; I.s.solve_time = 0.0; I.s.slot = slot; I.s.pend_stage = 0; I.s.pend_clock = 0;
       I.s.n_refactor = 0; I.s.n_factor_Q = 0; I.s.n_sweeps = 0; I.s.n_rank1 = 0; I.s.n_solve = 0;
-      I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0; I.s.n_fused_solve = 0; I.s.guard_redo = 0; I.s.n_guard_refactor = 0;
+      I.s.n_sigma_updates = 0; I.s.n_boost_gamma = 0; I.s.n_fused_solve = 0; I.s.guard_redo = 0; I.s.n_guard_refactor = 0; I.s.guard_spent = 0;
       I.s.ticks_total = 0; I.s.ticks_factor = 0; I.s.ticks_update = 0; I.s.ticks_solve = 0; I.s.ticks_linesearch = 0; I.s.ticks_resid = 0;
       for (int k = 0; k < QPG_NDBG; k++) I.s.ticks_dbg[k] = 0;
       I.s.ticks_dbg[QPG_CNT_PLACEMENT] = I.S.placement;
@@ -1076,14 +1076,19 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
        * c->status only when !DLONG).  Fuzz case 701 / 114 (LP, sigma up to 1e9 against 1 / gamma = 1e-7).  Free on healthy steps: two compares
        * on scalars the line search has.  (A second trigger -- an update that leaves a pivot <= 0 in a convex QP -- was built in round 6 and taken
        * out: on LPs whose H is singular by construction it fires at every step, 80 000 times in campaign 701, and moves healthy trajectories.) */
-      if (action == 0 || action == 2) {
+      if ((action == 0 || action == 2 || redo) && !I.s.guard_spent) {
         const double ge = I.s.eta, gb = I.s.beta;
         const bool bad = !(qabs(ge) <= 1.7976931348623157e308) || !(qabs(gb) <= 1.7976931348623157e308);
         if (QP_UNIFORM((int)bad) != 0) {
           __syncthreads();
-          if (tid == 0) { I.s.guard_redo = 1; I.s.n_guard_refactor++; I.s.ticks_linesearch += t3 - t2; }
-          __syncthreads();
-          continue;
+          if (redo) { /* the fresh factorisation gives a non-finite direction too: nothing to repair (a NaN right-hand side, a singular H): the step is taken as it is, like the reference's, and the guard stays off for the rest of this solve */
+            if (tid == 0) I.s.guard_spent = 1;
+            __syncthreads();
+          } else {
+            if (tid == 0) { I.s.guard_redo = 1; I.s.n_guard_refactor++; I.s.ticks_linesearch += t3 - t2; }
+            __syncthreads();
+            continue;
+          }
         }
       }
       /* iteration.c:219-228 */

@@ -77,7 +77,8 @@ typedef struct {
   double pend_gam;
   int64_t pend_clock; /* device clock (100 MHz, the same counter in every launch) when the iteration was suspended: the time the host's
                          kernels take until it resumes is added to solve_time, so that run_time and time_limit see wall time (qpalm.c:680-723) */
-  int32_t guard_redo, n_guard_refactor; /* guard_redo: the Newton direction of the last pass was not finite on an UPDATED factor (a pivot went through zero inside a sweep):
+  int32_t guard_redo, n_guard_refactor, guard_spent, guard_pad; /* guard_spent: a redone step came out non-finite as well (the right-hand side is not finite, or H is singular by construction): the guard is off for the rest of this solve */
+  /* (the two below:) */ /* guard_redo: the Newton direction of the last pass was not finite on an UPDATED factor (a pivot went through zero inside a sweep):
                                            the next pass refactorises and solves again instead of stepping (dev_solve; the oracle restates the same guard); the count of such passes */
   int32_t dual_pending, kkt_first; /* kkt_first: solver->first_factorization (types.h:176), KKT path; dual_pending: the factor of Q and the initial dual objective (qpalm.c:459-468) are still to be computed */
   /* work counters (device side statistics for the roofline accounting in bench.py) */

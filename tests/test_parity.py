@@ -740,11 +740,12 @@ def test_work_queue_starts_the_longest_previous_solves_first(ctx):
     (k_queue_order: the tail of the launch is then made of short solves; identity before the first solve).  The order must be exactly that
     permutation, and must not change any result: the second solve equals the first bit for bit, and both equal the oracle."""
     ctx.set_option("max_slots", 2)
-    n, m = sizes(ctx, (24, 48), (100, 200))
+    n, m = sizes(ctx, (24, 48), (300, 600))   # (on the hardware: the 512-thread instance, whose slot count is max_slots itself)
     probs = [random_qp(n, m, seed=520 + k, density_A=max(0.01, 4.0 / n), density_M=max(0.005, 2.0 / n)) for k in range(7)]
     try:
         bt = _compare_solve(ctx, probs, dict(eps_abs=1e-6, eps_rel=1e-6, verbose=0))
         B = len(probs)
+        assert bt.launch_shape()[0] < B                                                    # the launch goes through the work queue
         assert [int(bt.ivec("queue_order", k, 1)[0]) for k in range(B)] == list(range(B))     # no previous solve: index order
         x1, y1 = [a.copy() for a in bt.solution()]
         cost = [float(bt.stats(k).ms_total) for k in range(B)]
