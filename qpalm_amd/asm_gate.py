@@ -40,10 +40,16 @@ def _dst_src(ins):
 _SAVE = re.compile(r"^(v_mov_b(32|64)_e32\s+v\[?[0-9:]+\]?,\s*v\[?[0-9:]+\]?$|v_accvgpr_(read|write)_b32\s+[av]\d+,\s*[av]\d+$|scratch_store_\w+\s)")
 
 
+_EXEC_COPY = re.compile(r"^s_mov_b64\s+(s\[\d+:\d+\]),\s*exec$")
+_SAND = re.compile(r"^s_and_b64\s+(s\[\d+:\d+\]),\s*(s\[\d+:\d+\]|exec|vcc),\s*(s\[\d+:\d+\]|exec|vcc)$")
+_EXEC_FROM = re.compile(r"^s_mov_b64\s+exec,\s*(s\[\d+:\d+\])$")
+
+
 def scan(path):
     """[(function, block label, line, instruction, saves_outside_value)] for every vector instruction between a block label and the
     exec restore of that block"""
     fn, out, block, pending, written = None, [], None, [], set()
+    exec_copies, narrowed = set(), set()
     for ln, l in enumerate(open(path, errors="replace"), 1):
         s = l.strip()
         m = re.match(r"^(_Z\w+|\w+):\s*(;.*)?$", l)
@@ -51,10 +57,24 @@ def scan(path):
             fn = m.group(1)
         if re.match(r"^\.LBB\d+_\d+:", l):
             block, pending, written = s.split(":")[0], [], set()
+            exec_copies, narrowed = set(), set()
             continue
         if block is None or not s or s.startswith(";") or s.startswith("."):
             continue
         op = s.split()[0]
+        # `s_mov_b64 s[a:b], exec` ... `s_and_b64 s[c:d], s[a:b], cond` ... `s_mov_b64 exec, s[c:d]` is the ENTRY of a divergent region: exec is narrowed to
+        # a subset of what it is in this block, whatever stands in front of it ran with the block's full mask (round 6: the loop preheaders of
+        # qp128::k_solve took this shape and the gate, which treated every write of exec as a restore, called their copies of `n` a fault)
+        m1 = _EXEC_COPY.match(s)
+        if m1:
+            exec_copies.add(m1.group(1))
+        m2 = _SAND.match(s)
+        if m2 and ((m2.group(2) in exec_copies or m2.group(2) == "exec") or (m2.group(3) in exec_copies or m2.group(3) == "exec")):
+            narrowed.add(m2.group(1))
+        m3 = _EXEC_FROM.match(s)
+        if m3 and m3.group(1) in narrowed:
+            block = None
+            continue
         if _EXEC_RESTORE.match(s):
             out.extend((fn, block, pl, ps, outside) for (pl, ps, outside) in pending)
             block = None

@@ -728,7 +728,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     if (redo) {
       la = V.kkt ? 8 : 1; action = 1; kind = QP_KIND_NEWTON; nchange = 0; /* the active sets and nb_enter / nb_leave of the step stay (they are read again, B4) */
       __syncthreads();
-      if (tid == 0) I.s.guard_redo = 0;
+      if (tid == 0) { I.s.guard_redo = 0; I.s.guard_spent = 2; } /* 2: this pass is the redone one (read again after its line search) */
       __syncthreads();
     } else
     if (resume) {
@@ -1076,19 +1076,22 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
        * c->status only when !DLONG).  Fuzz case 701 / 114 (LP, sigma up to 1e9 against 1 / gamma = 1e-7).  Free on healthy steps: two compares
        * on scalars the line search has.  (A second trigger -- an update that leaves a pivot <= 0 in a convex QP -- was built in round 6 and taken
        * out: on LPs whose H is singular by construction it fires at every step, 80 000 times in campaign 701, and moves healthy trajectories.) */
-      if ((action == 0 || action == 2 || redo) && !I.s.guard_spent) {
+      {
+        const int gs = QP_UNIFORM(I.s.guard_spent); /* 0: armed, 1: spent, 2: this pass is the redone step */
         const double ge = I.s.eta, gb = I.s.beta;
         const bool bad = !(qabs(ge) <= 1.7976931348623157e308) || !(qabs(gb) <= 1.7976931348623157e308);
-        if (QP_UNIFORM((int)bad) != 0) {
+        const int what = ((action == 0 || action == 2 || gs == 2) && gs != 1 && bad) ? ((gs == 2) ? 2 : 1) : ((gs == 2) ? 3 : 0);
+        const int w = QP_UNIFORM(what);
+        if (w != 0) {
           __syncthreads();
-          if (redo) { /* the fresh factorisation gives a non-finite direction too: nothing to repair (a NaN right-hand side, a singular H): the step is taken as it is, like the reference's, and the guard stays off for the rest of this solve */
-            if (tid == 0) I.s.guard_spent = 1;
-            __syncthreads();
-          } else {
-            if (tid == 0) { I.s.guard_redo = 1; I.s.n_guard_refactor++; I.s.ticks_linesearch += t3 - t2; }
-            __syncthreads();
-            continue;
+          /* 1: redo with a fresh factorisation.  2: the fresh factorisation gives a non-finite direction too -- nothing to repair (a NaN right-hand side, an H that is
+           * singular by construction): the step is taken as it is, like the reference's, and the guard stays off for the rest of this solve.  3: the redone step is fine: re-arm */
+          if (tid == 0) {
+            if (w == 1) { I.s.guard_redo = 1; I.s.n_guard_refactor++; I.s.ticks_linesearch += t3 - t2; }
+            else I.s.guard_spent = (w == 2) ? 1 : 0;
           }
+          __syncthreads();
+          if (w == 1) continue;
         }
       }
       /* iteration.c:219-228 */

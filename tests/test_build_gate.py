@@ -87,3 +87,28 @@ def test_gate_flags_copies_ahead_of_the_exec_restore(tmp_path):
     assert len(mod.scan(str(phi))) == 4 and mod.copies(mod.scan(str(phi))) == []
     # (v_writelane_b32 ignores EXEC: an SGPR spill into a VGPR lane is safe wherever it sits)
     assert [f[3].split()[0] for f in mod.copies(mod.scan(str(sp)))] == ["scratch_store_dword", "v_accvgpr_write_b32"]
+
+
+# round 6: the ENTRY of a divergent region written as copy-of-exec / s_and / s_mov exec: exec is narrowed, the copy in front of it ran with
+# the block's full mask -- not the fault (the loop preheaders of qp128::k_solve after the Newton-direction guard went in)
+REGION_ENTRY = """
+_ZN5qp1287k_solveILi1EEEv8qpg_viewii:
+.LBB82_1016:                            ; %.preheader74.i
+	s_mov_b64 s[0:1], exec
+	v_readlane_b32 s2, v126, 54
+	v_readlane_b32 s3, v126, 55
+	s_and_b64 s[2:3], s[0:1], s[2:3]
+	v_mov_b32_e32 v8, v124
+	s_mov_b64 exec, s[2:3]
+	s_cbranch_execz .LBB82_1019
+"""
+
+
+def test_gate_does_not_flag_the_entry_of_a_divergent_region(tmp_path):
+    mod = _scan()
+    f = tmp_path / "entry.s"
+    f.write_text(REGION_ENTRY)
+    assert mod.copies(mod.scan(str(f))) == []
+    g = tmp_path / "restore.s"   # ... while the same copy ahead of a restore from a register the block did not derive from exec stays flagged
+    g.write_text(REGION_ENTRY.replace("s_and_b64 s[2:3], s[0:1], s[2:3]", "s_nop 0"))
+    assert [x[3] for x in mod.copies(mod.scan(str(g)))] == ["v_mov_b32_e32 v8, v124"]
