@@ -91,6 +91,41 @@ __global__ void k_mfma_indep(double *out, double a, double b) {
   }
   STAMP1(4 * N) out[threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
 }
+/* v_permlane32_swap on a dependent chain (the hand-over of QP_SPLIT_A) */
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double lower_to_upper(double keep, double src) {
+  const u2v a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(keep), (unsigned)__double2loint(src), false, false);
+  const u2v b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(keep), (unsigned)__double2hiint(src), false, false);
+  return __hiloint2double((int)b[0], (int)a[0]);
+}
+__global__ void k_swap_dep(double *out, double a, double b) {
+  double v = out[threadIdx.x], k = v + 1.0;
+  STAMP0
+  for (int i = 0; i < N; i++) {
+    v = lower_to_upper(k, v); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v) : "v"(a), "v"(b));
+    v = lower_to_upper(k, v); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v) : "v"(a), "v"(b));
+  }
+  STAMP1(2 * N) out[threadIdx.x] = v + k;   /* per (two swaps + one FMA) */
+}
+/* one step of the split loop: two swaps, sixteen DPP FMAs -- against thirty-two DPP FMAs (the unsplit column) */
+#define DPP8 DPP2(0) DPP2(1) DPP2(2) DPP2(3) DPP2(4) DPP2(5) DPP2(6) DPP2(7)
+__global__ void k_split_step(double *out, double a, double b) {
+  double w = out[threadIdx.x], l = w + 1.0, k = w + 2.0;
+  STAMP0
+  for (int i = 0; i < N; i++) {
+    l = lower_to_upper(k, l);
+    asm volatile("s_nop 1\n\t" DPP8 : "+&v"(w), "+&v"(l) : "v"(a), "v"(b));
+  }
+  STAMP1(N) out[threadIdx.x] = w + l;
+}
+__global__ void k_unsplit_step(double *out, double a, double b) {
+  double w = out[threadIdx.x], l = w + 1.0;
+  STAMP0
+  for (int i = 0; i < N; i++) {
+    asm volatile("s_nop 1\n\t" DPP8 "s_nop 1\n\t" DPP8 : "+&v"(w), "+&v"(l) : "v"(a), "v"(b));
+  }
+  STAMP1(N) out[threadIdx.x] = w + l;
+}
 int main() {
   double *d; hipMalloc(&d, 8192 * 8); hipMemset(d, 0, 8192 * 8);
   double r;
@@ -105,6 +140,9 @@ int main() {
     RUN("v_fmac_f64_dpp pair, dependent, lanes 32..63 off", k_dpp_dep, threads, d, 1e-9, 1e-9, 1)
     RUN("v_fmac_f64_dpp, 8 independent", k_dpp_indep, threads, d, 1e-9, 1e-9)
     RUN("halved chain: 5 instructions per RANK, 1 on the chain", k_halfchain, threads, d, 1e-9, 1e-9)
+    RUN("2 x v_permlane32_swap + 1 FMA, dependent", k_swap_dep, threads, d, 1e-9, 1e-9)
+    RUN("split step: 2 swaps + mov + 16 DPP FMAs", k_split_step, threads, d, 1e-9, 1e-9)
+    RUN("unsplit step: 32 DPP FMAs", k_unsplit_step, threads, d, 1e-9, 1e-9)
     RUN("v_mfma_f64_16x16x4_f64, dependent (1024 MACs each)", k_mfma_dep, threads, d, 1e-9, 1e-9)
     RUN("v_mfma_f64_16x16x4_f64, 4 independent", k_mfma_indep, threads, d, 1e-9, 1e-9)
   }
