@@ -191,7 +191,11 @@ int  qpg_batch_launch_shape(qpg_batch *bt, qpg_int *workgroups, qpg_int *threads
 /* The sparse L D L' (round 5): replaces what solver_interface.c:319-370, 523-541 hands to cholmod_analyze / cholmod_factorize for
  * factors that are sparse or have more than 8192 rows (context option "sparse_factor": -1 automatic for > 8192 rows, 1 always,
  * 0 never; Schur path, no dual termination).  nnzL: entries of the member's strict lower triangle; device_bytes: the block that holds
- * the symbolic arrays of all members and the values of all resident factors.  QPG_ERR_UNSUPPORTED on a batch with dense factors. */
+ * the symbolic arrays of all members and the values of all resident factors.  QPG_ERR_UNSUPPORTED on a batch with dense factors.
+ * Where its policy is not the reference's: rows that enter or leave the active set, and rows whose penalty changed
+ * (ldlupdate_sigma_changed, solver_interface.c:443-503), are rank-1 updates along their elimination-tree paths only while
+ * 2 x changed rows x tree height < n; beyond that the factor is rebuilt (on a chain-like tree -- a band under the natural ordering --
+ * a path is the whole matrix).  QPGStats.n_refactor / n_rank1 then differ from the reference's split; the matrices factorised do not. */
 int  qpg_batch_sparse_info(qpg_batch *bt, qpg_int idx, qpg_int *nnzL, qpg_int *device_bytes);
 /* The ordering of member idx's sparse factor, P H P' = L D L': perm[new] = old (n entries), and the height of its elimination tree.
  * The reference configures CHOLMOD_NATURAL (solver_interface.c:530-540: identity); context option "sparse_ordering" = 1 orders by

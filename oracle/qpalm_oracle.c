@@ -90,7 +90,8 @@ struct oq_workspace {
    * simplicial analyze / factorize / solve do -- for problems whose n^2 panel is out of reach (n = 20 000 .. 100 000).  Every entry
    * receives the operations of the dense routines above in the same order (structural zeros are skipped, and a skipped operation adds
    * an exact zero), so the dense mode pins it: tests/test_sparse_factor.py compares the two bit for bit.  In this mode every change
-   * of the active set or of sigma refactorises (no rank updates), which is what the engine's sparse factor does. */
+   * of the active set or of sigma refactorises in mode 2 (what pins the mode); in mode 1 the rows that enter or leave and the rows whose sigma
+   * changed are applied as rank-1 updates along their elimination-tree paths where that is cheaper than rebuilding (the engine's rule). */
   int sparse_mode;
   oq_int sp_nlev;                                   /* height of the elimination tree (levels) */
   oq_int *sp_Lp, *sp_Li, *sp_Rp, *sp_Rk, *sp_Rpos; /* pattern of L by columns (strict lower, rows ascending) and by rows (columns ascending) */
@@ -761,6 +762,7 @@ static void initialize_sigma(oq_workspace *w) { /* iteration.c:50-84 */
   sp_scale_col(&w->At_sqrt_sigma, w->At_scale);
 }
 
+static int sparse_update_pays(const oq_workspace *w, oq_int nchange);
 void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
   size_t m = (size_t)w->m;
   const oq_settings *st = &w->settings;
@@ -801,8 +803,14 @@ void oq_update_sigma(oq_workspace *w) { /* iteration.c:86-145 */
       w->reset_newton = 1;
     return;
   }
-  if (w->sparse_mode) { /* no rank updates on the sparse factor: any change of sigma refactorises (like the engine's sparse mode) */
-    if ((st->proximal && w->gamma < st->gamma_max) || w->nb_sigma_changed > 0) w->reset_newton = 1;
+  if (w->sparse_mode) {
+    /* sparse storage: the reference's rule (below) with one more condition -- the changed rows are applied as path updates only where walking
+     * their elimination-tree paths is cheaper than rebuilding the factor (sparse_update_pays: the engine's rule, mode 1); in mode 2 every
+     * change refactorises (what pins the mode against the dense one).  (Through round 5 every change of sigma refactorised in both modes.) */
+    if ((st->proximal && w->gamma < st->gamma_max) ||
+        (w->nb_sigma_changed > OQ_MIN(st->max_rank_update_fraction * (w->n + w->m), 0.25 * st->max_rank_update)) ||
+        (w->nb_sigma_changed > 0 && !(w->sp_Lp && sparse_update_pays(w, w->nb_sigma_changed)))) w->reset_newton = 1;
+    else if (w->nb_sigma_changed > 0) oq_ldlupdate_sigma_changed(w);
     return;
   }
   if ((st->proximal && w->gamma < st->gamma_max) ||

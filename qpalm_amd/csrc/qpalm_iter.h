@@ -297,6 +297,9 @@ QPN void dev_ldlupdate_sigma_scale(const QpArrays &a, int nchg) {
   __syncthreads();
 }
 
+/* sparse factor: a rank-1 update walks the row's elimination-tree path (about `nlev` dependent steps); cheaper than rebuilding the factor while
+ * 2 nchange nlev < n (qpalm_sparse.h: sp_updown) */
+QPD bool sp_update_pays(int nchange, int nlev, int n) { return (long long)nchange * (long long)nlev * 2 < (long long)n; }
 /* Part 1: new sigma, rescaled At_sqrt_sigma, list of changed rows (in a.enter()).  Returns the number
  * of rank-1 updates ldlupdate_sigma_changed has to apply (0: nothing to do or a refactorisation was
  * requested); the update itself runs at dev_solve's single linear-algebra site, then part 2. */
@@ -341,10 +344,19 @@ QPP int dev_update_sigma_pre(const qpg_view &V, const QpArrays &a, IterShared &I
   if (V.offload && V.update_rank_threshold >= 0) thr = qmin(thr, (double)V.update_rank_threshold); /* coop mode: beyond its threshold the factor is rebuilt by many workgroups
                                                                         instead of updated by one (speed policy, same matrix) */
   int nupd = 0;
-  if (V.sparse) { /* sparse factor (qpalm_sparse.h): no rank updates -- any change of sigma refactorises at the next Newton step */
-    if ((qp_prox(st, I.s) && I.s.gamma < qp_gamma_max(st, I.s)) || nchg > 0) { if (tid == 0) I.s.reset_newton = 1; }
+  if (V.sparse) {
+    /* sparse factor (qpalm_sparse.h): ldlupdate_sigma_changed as the reference has it (solver_interface.c:443-503) -- rank-1 updates with the scaled rows along
+     * their elimination-tree paths -- where walking the paths is cheaper than rebuilding (sp_update_pays, the rule of the entering / leaving rows); else the
+     * factor is marked stale and the next Newton step refactorises.  (Through round 5 every change of sigma refactorised here.) */
+    const bool pays = sp_update_pays(nchg, V.sp_nlev[a.b], n);
+    if ((qp_prox(st, I.s) && I.s.gamma < qp_gamma_max(st, I.s)) || ((double)nchg > thr) || (nchg > 0 && !pays)) {
+      if (tid == 0) I.s.reset_newton = 1;
+    } else if (nchg > 0) {
+      dev_ldlupdate_sigma_scale(a, nchg);
+      nupd = nchg;
+    }
     __syncthreads();
-    return 0;
+    return nupd;
   }
   if (V.kkt) {
     /* FACTORIZE_KKT (iteration.c:135-144, solver_interface.c:463-481): every branch that changes anything ends in
@@ -988,11 +1000,12 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
     double gersh_ub = 0.0;
     if constexpr (SPARSE) {
       /* sparse factor (qpalm_sparse.h): rows entering / leaving the active set are rank-1 updates along their elimination-tree
-       * paths where that pays, a refactorisation otherwise; a change of sigma marks the factor stale (dev_update_sigma_pre), as the
-       * reference does under FACTORIZE_KKT (iteration.c:135-144) */
+       * paths where that pays, a refactorisation otherwise; changed penalties likewise (la == 4: ldlupdate_sigma_changed as path updates with the scaled
+       * rows, dev_update_sigma_pre decides) */
       const SpArrays SP = sp_arrays(V, b, slot, Dg);
       if (la == 2 && !sp_update_pays(nchange, SP.nlev, n)) { la = 1; action = 1; } /* a chain-like tree: refactorising is cheaper than walking it per row */
       if (la == 2) sp_updown(V, b, n, SP, a.enter(), I.s.nb_enter, a.leave(), I.s.nb_leave);
+      else if (la == 4) sp_updown(V, b, n, SP, a.enter(), n_sig, a.leave(), 0); /* ldlupdate_sigma_changed: the rows listed in enter[], scaled by dev_ldlupdate_sigma_scale */
       else if (la == 1 || la == 3) sp_factor(V, b, n, SP, la == 1, prox != 0, gam);
       else if (la == 5) gersh_ub = sp_gershgorin(V, b, n, SP, I.S);
     } else

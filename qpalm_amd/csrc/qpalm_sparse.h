@@ -211,7 +211,7 @@ QPN double sp_gershgorin(const qpg_view &V, int b, const int n, const SpArrays &
  * the oracle's form (oq_dense_ldl_rank1: a = alpha +- w_j^2 / d_j, d_j <- d_j a / alpha, gamma = -+ w_j / (d_j a)), per entry
  * w_i <- w_i - w_j l_ij, l_ij <- l_ij - gamma w_i.  Columns off the path are not touched.  Cost: one chain step (a few dependent HBM
  * round trips) per path column -- cheap on bushy trees (block structure), hopeless on a chain (band matrix): sp_update_pays decides. */
-QPD bool sp_update_pays(int nchange, int nlev, int n) { return (long long)nchange * (long long)nlev * 2 < (long long)n; }
+/* (sp_update_pays: qpalm_iter.h, in front of dev_update_sigma_pre, which applies the same rule to changed penalties) */
 QPN void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S, const int *up, int n_up, const int *dn, int n_dn) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1);

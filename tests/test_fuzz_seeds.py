@@ -99,11 +99,15 @@ def test_fuzz_nonconvex_campaign(ctx):
     for seed, count, n_lo, n_hi, shift in plan:
         b, s = _campaign(ctx, seed, count, n_lo, n_hi, dict(nonconvex=1, q_shift=shift))
         bad += b; soft += s; total += count
-    _report(ctx, "N nonconvex", total, bad, soft)
+    by = _report(ctx, "N nonconvex", total, bad, soft)
     assert not bad, bad
-    # indefinite LDL' without pivoting: more counts are decided by rounding than in the convex campaigns (round 4: 37 of 610, of which
-    # seven are EMPTY random Hessians on which the reference's LOBPCG divides by the norm of a zero residual, nonconvex.c:75-77)
-    assert len(soft) <= max(2, (total * 8) // 100), soft
+    # indefinite LDL' without pivoting: more counts are decided by rounding than in the convex campaigns.  Round 6, with the running pivot in every
+    # sweep of a nonconvex QP and the buckets counted apart (hardware: 30 rounding-decided, 3 decided by the form of the rank-update recurrence, 10
+    # EMPTY random Hessians on which the reference's LOBPCG divides by the norm of a zero residual -- nonconvex.c:75-77 -- of 810): the allowance
+    # is per bucket, 5 % / 1 % / 2 % (it was 8 % of everything together through round 5)
+    assert by.get("rounding", 0) <= max(2, (total * 5) // 100), (by, soft)
+    assert by.get("engine-form", 0) <= max(1, total // 100), (by, soft)
+    assert by.get("singular", 0) <= max(1, (total * 2) // 100), (by, soft)
 
 
 def test_fuzz_dual_termination_campaign(ctx):
