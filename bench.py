@@ -331,7 +331,7 @@ def mpc_problems(B, rank, rng):
     return probs
 
 
-def mpc160_line(ctx, B, kkt, steps, warmup=1):
+def mpc160_line(ctx, B, kkt, steps, warmup=1, traffic_dir=None):
     """BASELINE.json config 3 next to the headline: B mpc-160 QPs through a warm-started receding-horizon
     sequence (update_bounds + warm start from the previous solution, simulations/randomMPCsequential.m:158-177), Schur panel with
     rank updates or (kkt) the (n+m) x (n+m) KKT panel with row additions / deletions.  Returns the sub-object of the JSON line."""
@@ -387,7 +387,8 @@ def mpc160_line(ctx, B, kkt, steps, warmup=1):
             tot[k] += pb[k]
     fused_away = tot.pop("solve_fused_away")
     alg = sum(tot.values()) - fused_away
-    traffic, traffic_src = pmc_traffic("mpc160_kkt_pmc_traffic.json" if kkt else "mpc160_pmc_traffic.json", (B, n, m))
+    tname = "mpc160_kkt_pmc_traffic.json" if kkt else "mpc160_pmc_traffic.json"
+    traffic, traffic_src = pmc_traffic(tname, (B, n, m), None, os.path.join(traffic_dir, tname) if traffic_dir else None)
     roof = {"bound": "hbm", "kernel": "k_solve (persistent, one workgroup per QP), one warm-started step", "achieved": alg / (kms[-1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg / (kms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kms[-1], "algorithmic_bytes_per_launch": alg, "fused_away_bytes_per_launch": fused_away,
             "bytes_per_qp": {k: v / B for k, v in tot.items()}, "traffic": traffic, "traffic_source": traffic_src,
@@ -702,7 +703,8 @@ def worker(args):
         if world == 1 and args.workload == "random-1000" and not args.no_mpc and not args.kkt and not args.n and not args.lib:
             # config 3 in the driver's record: Schur and KKT mode, a few warm-started steps each (outside the timed region of the headline)
             try:
-                out["mpc160"] = {"schur": mpc160_line(ctx, 8192, False, 5), "kkt": mpc160_line(ctx, 2048, True, 3)}
+                tdir = os.path.dirname(os.path.abspath(args.traffic_json)) if args.traffic_json else None   # (the evidence run: the summaries sit next to the headline's)
+                out["mpc160"] = {"schur": mpc160_line(ctx, 8192, False, 5, traffic_dir=tdir), "kkt": mpc160_line(ctx, 2048, True, 3, traffic_dir=tdir)}
             except Exception as e:   # never lose the headline line over the side figures
                 out["mpc160"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:

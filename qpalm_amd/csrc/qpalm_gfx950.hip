@@ -5,6 +5,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <string>
 #include <type_traits>
 
@@ -173,10 +174,24 @@ static thread_local hipStream_t g_rt_user_stream = 0; /* where plain launches an
 static void rt_use_stream(int k) {
   if (k < 0) { g_rt_user_stream = 0; g_rt_stream = 0; return; }
   k %= RT_SIDE_STREAMS;
-  if (!g_rt_side[k] && hipStreamCreate(&g_rt_side[k]) != hipSuccess) { g_rt_side[k] = 0; (void)hipGetLastError(); }
+  if (!g_rt_side[k]) {
+    const hipError_t e = hipStreamCreate(&g_rt_side[k]);
+    if (e != hipSuccess) { /* the chain runs on the null stream instead (correct, not concurrent); said once, not swallowed */
+      g_rt_side[k] = 0; (void)hipGetLastError();
+      static thread_local bool told = false;
+      if (!told) { told = true; g_rt_err = std::string("hipStreamCreate (coop side stream): ") + hipGetErrorString(e) + " -- the members' chains run one after the other"; fprintf(stderr, "qpalm_gfx950: %s\n", g_rt_err.c_str()); }
+    }
+  }
   g_rt_user_stream = g_rt_side[k];
   g_rt_stream = g_rt_user_stream;
 }
+/* the calling thread's side streams go with the context that used them (they are created lazily per host thread; a thread that ran coop
+ * solves and drops its context no longer leaks them) */
+static void rt_release_streams() {
+  g_rt_user_stream = 0; g_rt_stream = 0;
+  for (int k = 0; k < RT_SIDE_STREAMS; k++) if (g_rt_side[k]) { (void)hipStreamDestroy(g_rt_side[k]); g_rt_side[k] = 0; }
+}
+#define RT_RELEASE_STREAMS() rt_release_streams()
 #define RT_USE_STREAM(k) rt_use_stream(k)
 #define RT_LAUNCH(kernel, grid, block, shmem, ...)                                         \
   do {                                                                                      \

@@ -40,6 +40,7 @@ typedef int rt_graph_t;
 #define RT_GRAPH_LAUNCH(exec) 0
 #define RT_GRAPH_FREE(exec) (void)0
 #define RT_USE_STREAM(k) (void)(k)
+#define RT_RELEASE_STREAMS() do { } while (0)
 #define RT_TIMED_LAUNCH(ms, kernel, grid, block, shmem, ...)                                   \
   do {                                                                                         \
     auto t0_ = std::chrono::steady_clock::now();                                               \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence, run on the GPU box:  bash tools/evidence/round_artifacts.sh [round]   (outputs under gpurun_out/<round>/final/)
 # Copies to profiles/<round>/ are made by hand from the merged gpurun_out/.  Every step has its own timeout.
-R=${1:-r05}
+R=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/$R/final
 mkdir -p $OUT
@@ -16,12 +16,19 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-mpc > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktm -- python3 $REPO/bench.py --workload mpc-160 --steps 5 --no-cpu > $OUT/bench_mpc160_under_kernel_trace.json 2> $OUT/ktm.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktk -- python3 $REPO/bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt_under_kernel_trace.json 2> $OUT/ktk.err
+# config 3 (mpc-160), HBM bytes per warm-started launch: the same two counters in passes of their own (round 6: the roofline object of the mpc160 lines)
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_mpc_fetch -- python3 $REPO/bench.py --workload mpc-160 --steps 5 --no-cpu > $OUT/pmc_mpc_fetch_bench.json 2> $OUT/pmc_mpc_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_mpc_write -- python3 $REPO/bench.py --workload mpc-160 --steps 5 --no-cpu > $OUT/pmc_mpc_write_bench.json 2> $OUT/pmc_mpc_write.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_mpck_fetch -- python3 $REPO/bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/pmc_mpck_fetch_bench.json 2> $OUT/pmc_mpck_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_mpck_write -- python3 $REPO/bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/pmc_mpck_write_bench.json 2> $OUT/pmc_mpck_write.err
 cd $OUT
 find kt -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_default.csv \;
 find ktm -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_mpc160.csv \;
 find ktk -name "*kernel_stats*.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_bench_mpc160_kkt.csv \;
 python3 $REPO/tools/evidence/pmc_summary.py $OUT $REPO > $OUT/k_solve_pmc_traffic.json
-rm -rf kt ktm ktk pmc_fetch pmc_write pmc_sq
+python3 $REPO/tools/evidence/pmc_summary.py $OUT $REPO mpc_ > $OUT/mpc160_pmc_traffic.json
+python3 $REPO/tools/evidence/pmc_summary.py $OUT $REPO mpck_ > $OUT/mpc160_kkt_pmc_traffic.json
+rm -rf kt ktm ktk pmc_fetch pmc_write pmc_sq pmc_mpc_fetch pmc_mpc_write pmc_mpck_fetch pmc_mpck_write
 cd $REPO
 # the reported line: same build, same box, traffic from the passes above (bench.py checks the source and library hashes recorded in the summary)
 timeout 1200 python bench.py --traffic-json $OUT/k_solve_pmc_traffic.json > $OUT/bench_default.json 2> $OUT/bench_default.err
@@ -30,6 +37,9 @@ timeout 600 python bench.py --workload mpc-160 --steps 5 > $OUT/bench_mpc160.jso
 timeout 600 python bench.py --workload mpc-160 --kkt --batch 2048 --steps 3 --no-cpu > $OUT/bench_mpc160_kkt.json 2>> $OUT/bench_default.err
 timeout 600 python bench.py --workload mpc-160 --steps 5 --small-workgroups 3 --no-cpu > $OUT/bench_mpc160_256_thread_instance.json 2>> $OUT/bench_default.err
 timeout 600 python bench.py --sweep-ranks 32 --no-cpu --no-mpc > $OUT/bench_sweep_ranks_32.json 2>> $OUT/bench_default.err
+# the price of the pivot guard, same box: default (guarded prefix tree) / unguarded tree / the running pivot in every column
+for v in -1 0 1; do timeout 600 python bench.py --no-cpu --no-mpc --sequential-rank-sums $v > $OUT/bench_rank_sums_$v.json 2>> $OUT/bench_default.err; done
+timeout 120 tools/evidence/mb_f64rate > $OUT/mb_f64rate.txt 2>&1
 bash tools/evidence/phase_traffic.sh $R/final/phase_traffic > $OUT/phase_traffic.log 2>&1
 timeout 300 python tools/evidence/sweep_probe.py cur --reps 4 --ranks 16 8 > $OUT/sweep_probe.txt 2>> $OUT/bench_default.err
 timeout 300 python tools/evidence/setup_timing.py 8192 > $OUT/setup_timing.txt 2>&1
