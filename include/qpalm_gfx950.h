@@ -190,7 +190,7 @@ int  qpg_batch_num_unfinished(qpg_batch *bt, qpg_int *count);
 int  qpg_batch_launch_shape(qpg_batch *bt, qpg_int *workgroups, qpg_int *threads, qpg_int *lds_bytes);
 /* The sparse L D L' (round 5): replaces what solver_interface.c:319-370, 523-541 hands to cholmod_analyze / cholmod_factorize for
  * factors that are sparse or have more than 8192 rows (context option "sparse_factor": -1 automatic for > 8192 rows, 1 always,
- * 0 never; Schur path, no dual termination).  nnzL: entries of the member's strict lower triangle; device_bytes: the block that holds
+ * 0 never; Schur path; dual termination keeps a second value array per slot for LD_Q, the factor of Q alone on the same pattern).  nnzL: entries of the member's strict lower triangle; device_bytes: the block that holds
  * the symbolic arrays of all members and the values of all resident factors.  QPG_ERR_UNSUPPORTED on a batch with dense factors.
  * Where its policy is not the reference's: rows that enter or leave the active set, and rows whose penalty changed
  * (ldlupdate_sigma_changed, solver_interface.c:443-503), are rank-1 updates along their elimination-tree paths only while

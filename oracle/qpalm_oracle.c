@@ -1907,7 +1907,7 @@ void oq_set_scalar(oq_workspace *w, const char *name, oq_float v) {
   else if (!strcmp(name, "reset_newton")) w->reset_newton = (int)v;
   else if (!strcmp(name, "updown_block")) w->updown_block = (int)v; /* > 1: the blocked multi-rank form of updown_columns (same bits, L streamed once per eight ranks) */
   else if (!strcmp(name, "newton_guard")) w->guard = (v != 0); /* 0: the reference's behaviour, no guard against a non-finite Newton direction (oq_workspace::guard) */
-  else if (!strcmp(name, "sparse_mode")) w->sparse_mode = (v != 0 && !w->kkt_mode && !w->settings.enable_dual_termination) ? (int)v : 0; /* before the first solve; 1 = path
+  else if (!strcmp(name, "sparse_mode")) w->sparse_mode = (v != 0 && !w->kkt_mode) ? (int)v : 0; /* before the first solve; 1 = path
                                                          updates where they pay (the engine's rule), 2 = every change refactorises (what pins the mode against the dense one) */
   else if (!strcmp(name, "eps_abs_in")) w->eps_abs_in = v;
   else if (!strcmp(name, "eps_rel_in")) w->eps_rel_in = v;

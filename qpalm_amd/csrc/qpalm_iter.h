@@ -680,6 +680,27 @@ QPP double dev_dual_objective(const qpg_view &V, const QpArrays &a, int b, const
 #include "qpalm_kkt.h"
 #include "qpalm_sparse.h"
 
+/* ... and with the sparse factor (round 6): LD_Q = the L D L' of Q alone on the pattern of the main factor (a superset of Q's own: the entries
+ * outside it come out as exact zeros), in a second value array per slot; the same sums */
+QPP double dev_dual_objective_sp(const qpg_view &V, const QpArrays &a, int b, const SpArrays &SQ, IterShared &I) {
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  double *rhs = V.dual_rhs + (size_t)b * n, *sol = a.temp_n();
+  __syncthreads();
+  for (int j = tid; j < n; j += QP_T) { const double r = a.Aty()[j] + 1.0 * a.q()[j]; rhs[j] = r; sol[j] = r; }
+  __syncthreads();
+  if (QP_CALL_BLOCK()) sp_solve(n, SQ, sol);
+  double vm[1] = {0.0}, vs[2] = {0.0, 0.0};
+  for (int j = tid; j < n; j += QP_T) vs[0] += rhs[j] * sol[j];
+  for (int i = tid; i < m; i += QP_T) { const double yv = a.y()[i]; vs[1] += yv > 0 ? yv * a.bmax()[i] : yv * a.bmin()[i]; }
+  block_reduce<0, 2>(I.S, vm, vs);
+  double dobj = 0;
+  dobj -= 0.5 * vs[0];
+  dobj -= vs[1];
+  if (I.s.has_scaling) dobj *= I.s.sc_cinv;
+  dobj += V.c0[b];
+  return dobj;
+}
+
 /* =============================================================================================
  * the loop body of qpalm_solve (src/qpalm.c:484-711) for one QP; runs at most `budget` iterations
  * =========================================================================================== */
@@ -690,7 +711,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
   QpArrays a = qp_arrays(V, b);
   const int n = a.n, m = a.m, tid = threadIdx.x;
   double *L = V.L + (size_t)slot * V.ld * V.nfac, *Dg = V.Dg + (size_t)slot * V.nfac, *Wst = V.Wst + (size_t)slot * V.wst_stride;
-  double *LQ = V.LQ ? V.LQ + (size_t)slot * V.ld * V.nfac : nullptr, *DgQ = V.DgQ ? V.DgQ + (size_t)slot * V.nfac : nullptr;
+  double *LQ = V.LQ ? V.LQ + (SPARSE ? (size_t)slot * V.sp_nnzL : (size_t)slot * V.ld * V.nfac) : nullptr, *DgQ = V.DgQ ? V.DgQ + (size_t)slot * V.nfac : nullptr; /* (sparse: LQ = the values of LD_Q on the factor's pattern) */
   __syncthreads();
   if (tid == 0) {
     I.s = V.sc[b];
@@ -917,7 +938,9 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
         for (int j = tid; j < n; j += QP_T) a.Aty()[j] = a.Atyh()[j];
         __syncthreads();
         if (st.enable_dual_termination) { /* qpalm.c:543-583 */
-          const double dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
+          double dobj;
+          if constexpr (SPARSE) { SpArrays SQ = sp_arrays(V, b, slot, DgQ); SQ.Lx = LQ; dobj = dev_dual_objective_sp(V, a, b, SQ, I); }
+          else dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
           if (tid == 0) I.s.dual_objective = dobj;
           __syncthreads();
           if (QP_UNIFORM((int)(dobj > st.dual_objective_limit))) { /* same value in every lane: scalar branch */
@@ -1008,6 +1031,14 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       else if (la == 4) sp_updown(V, b, n, SP, a.enter(), n_sig, a.leave(), 0); /* ldlupdate_sigma_changed: the rows listed in enter[], scaled by dev_ldlupdate_sigma_scale */
       else if (la == 1 || la == 3) sp_factor(V, b, n, SP, la == 1, prox != 0, gam);
       else if (la == 5) gersh_ub = sp_gershgorin(V, b, n, SP, I.S);
+      else if (la == 7) { /* qpalm.c:459-468: LD_Q = the factor of Q alone (no A' Sigma A, no I / gamma) and the dual objective of the starting point */
+        SpArrays SQ = SP; SQ.Lx = LQ; SQ.Dg = DgQ;
+        sp_factor(V, b, n, SQ, false, false, gam);
+        const double dobj = dev_dual_objective_sp(V, a, b, SQ, I);
+        if (tid == 0) { I.s.dual_objective = dobj; I.s.dual_pending = 0; }
+        __syncthreads();
+        continue;
+      }
     } else
     if (resume) {
       if (la == 7) { /* LD_Q is ready (qpalm.c:459-468) */

@@ -52,7 +52,7 @@ QPD bool sp_level_needs_barrier(const SpArrays &S, int lev) {
   return (S.levptr[lev + 1] - S.levptr[lev] > 1) || (S.levptr[lev + 2] - S.levptr[lev + 1] > 1);
 }
 /* H = Q (+ A' Sigma_act A) (+ I / gamma) assembled column by column and factorised in the same pass (see the header).
- * Q_only_values: the second resident factor LD_Q of the dual objective is not supported in sparse mode (qpg_batch_create refuses). */
+ * with_AtSA = false, proximal = false: the second resident factor LD_Q of the dual objective (dev_solve, la == 7), into the value arrays the caller points S at. */
 QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, bool with_AtSA, bool proximal, double gamma) {
   /* a column per GROUP of lanes: the columns of a sparse factor are short (a band: half a dozen entries), so a wavefront takes gpw = 1, 2
    * or 4 columns of the level at a time (16 lanes each at 4) and a 512-thread workgroup up to 32 -- every step of a column is a chain of

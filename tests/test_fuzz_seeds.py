@@ -127,7 +127,7 @@ def test_fuzz_sparse_factor_campaign(ctx):
     symbolic analysis of every random pattern, fused assemble-and-factorise, path updates where they pay) against the oracle in its
     sparse-storage mode, which refactorises and updates by the same rule: status, iteration count, x and y as in the other campaigns."""
     plan = [(51, 6, 2, 40, -1), (53, 3, 30, 60, 1)] if ctx.kind == "emu" else [(51, 300, 2, 70, -1), (52, 60, 257, 420, -1), (53, 200, 30, 120, 1), (54, 40, 257, 420, 1)]
-    force = dict(factorization_method=1, enable_dual_termination=0)   # (last column: sparse_ordering -- 1 = every factor under a nested dissection)
+    force = dict(factorization_method=1)   # (round 6: dual termination as drawn -- a fifth of the cases; last column: sparse_ordering -- 1 = every factor under a nested dissection)
     bad, soft, total = [], [], 0
     ctx.set_option("sparse_factor", 1)
     try:

@@ -207,8 +207,8 @@ def test_sparse_factor_refuses_what_it_does_not_cover(ctx):
         with pytest.raises(Exception):
             bt.factor(0)                      # the single operations of solver_interface.h work on the dense panel
         bt.close()
-        # KKT mode and dual termination keep the dense factor even when the sparse one is asked for
-        for kw in (dict(factorization_method=0), dict(enable_dual_termination=1)):
+        # KKT mode keeps the dense factor even when the sparse one is asked for (dual termination no longer does: round 6, next test)
+        for kw in (dict(factorization_method=0),):
             bt = QpalmBatch(ctx, [p], ctx.default_settings(**dict(ST, **kw)))
             with pytest.raises(Exception):
                 bt.sparse_info(0)
@@ -217,6 +217,47 @@ def test_sparse_factor_refuses_what_it_does_not_cover(ctx):
             bt.close()
     finally:
         ctx.set_option("sparse_factor", -1)
+
+
+@pytest.mark.parametrize("kind,n,ordering", [("blocks", 96, 0), ("banded", 90, 1), ("random", 50, 0)])
+def test_sparse_factor_with_dual_termination_and_sigma_path_updates(ctx, kind, n, ordering):
+    """Round 6, two things the sparse factor refused or did differently from the reference through round 5:
+     * dual termination (qpalm.c:459-468, 545-583): the second resident factor LD_Q = L D L' of Q alone, here on the main factor's pattern in a
+       second value array; the dual objective at every outer iteration against the oracle's, and the DUAL_TERMINATED exit at the same iteration;
+     * ldlupdate_sigma_changed (solver_interface.c:443-503) as rank-1 path updates where the tree is bushy enough for them to pay, instead of
+       a refactorisation at every change of sigma: refactorisation and rank-1 counts equal the sparse-mode oracle's, which applies the same rule."""
+    p = random_qp(n, 2 * n, seed=7, density_A=0.06, density_M=0.04) if kind == "random" else sparse_qp(n, kind, seed=4)
+    ctx.set_option("sparse_factor", 1)
+    ctx.set_option("sparse_ordering", ordering)
+    try:
+        st = dict(ST, enable_dual_termination=1, dual_objective_limit=1e20)
+        bt = QpalmBatch(ctx, [p], ctx.default_settings(**st))
+        assert bt.sparse_info(0)[0] > 0                       # the batch really keeps the sparse factor
+        bt.solve()
+        o = oracle_sparse(p, bt.sparse_perm(0)[0], **st)
+        info, s = bt.info(0), bt.stats(0)
+        assert int(info.status_val) == o.status_val == 1 and int(info.iter) == int(o.info.iter)
+        assert abs(info.dual_objective - o.info.dual_objective) <= 1e-8 * max(1.0, abs(o.info.dual_objective)), (info.dual_objective, o.info.dual_objective)
+        assert abs(info.dual_objective - info.objective) <= 1e-4 * max(1.0, abs(info.objective))      # (and it IS the dual objective: no gap at the solution)
+        assert rel(bt.solution()[0][0], o.x) <= 1e-9 and rel(bt.solution()[1][0], o.y) <= 1e-9
+        assert int(s.n_refactor) == o.counter("n_refactor") and int(s.n_rank1) == o.counter("n_rank1")
+        if kind == "blocks":   # bushy tree: the penalties that change are path updates, so fewer factorisations than "every change refactorises" (mode 2)
+            o2 = ob.OracleQP(*p.args(), settings=ob.default_settings(**st)); o2.set_scalar("sparse_mode", 2); o2.solve()
+            assert int(s.n_sigma_updates) > 0 and int(s.n_refactor) < o2.counter("n_refactor")
+        bt.close()
+        # the early exit: a limit below the optimal value is crossed by the (increasing) dual objective on the way
+        d0 = float(o.info.dual_objective)
+        for lim in (d0 - 0.5 * abs(d0) - 1.0, d0 - 0.01 * abs(d0) - 1e-3):       # crossed by the starting point / late in the solve
+            st2 = dict(st, dual_objective_limit=lim)
+            bt = QpalmBatch(ctx, [p], ctx.default_settings(**st2))
+            bt.solve()
+            o2 = oracle_sparse(p, bt.sparse_perm(0)[0], **st2)
+            assert int(bt.info(0).status_val) == o2.status_val == 2 and int(bt.info(0).iter) == int(o2.info.iter), (lim, bt.info(0).status_val, o2.status_val)   # DUAL_TERMINATED
+            assert abs(bt.info(0).dual_objective - o2.info.dual_objective) <= 1e-8 * max(1.0, abs(o2.info.dual_objective))
+            bt.close()
+    finally:
+        ctx.set_option("sparse_factor", -1)
+        ctx.set_option("sparse_ordering", -1)
 
 
 def _kkt_check(p, x, y, tol=1e-5):

@@ -32,7 +32,7 @@ if sparse:
     ctx.set_option("sparse_factor", 1)
     if ordering is not None:
         ctx.set_option("sparse_ordering", int(ordering))
-    force.update(dict(factorization_method=1, enable_dual_termination=0))
+    force.update(dict(factorization_method=1))
 worst_dy_ratio = 0.0   # largest dy / derived bound among the cases that needed more than 1e-8 on y
 bad = 0    # fails the rule (or an exception)
 soft = 0   # passes, but not as an outright match: by bucket in `by` (rounding / engine-form / singular: tests/fuzz_cases.py, judge_case)
