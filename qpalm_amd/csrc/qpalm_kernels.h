@@ -491,6 +491,40 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op(qpg_view V, int b, int
   if (tid == 0) V.sc[b] = I.s;
 }
 
+/* ... the same operations on a batch that keeps the SPARSE factor (round 6; through round 5 they were refused): ldlcholQAtsigmaA / ldlchol of Q (+ I / gamma),
+ * the updates for entering, leaving and sigma-changed rows as path updates (always: the single operation has no "refactorise instead" policy), the solve.
+ * One instance (the sparse factor has no rows-per-thread variants). */
+__global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op_sparse(qpg_view V, int b, int op) {
+  __shared__ IterShared I;
+  const qpg_settings &st = *V.settings;
+  const QpArrays a = qp_arrays(V, b);
+  const int n = a.n, tid = threadIdx.x, slot = b;
+  if (tid == 0) { I.s = V.sc[b]; I.S.panel_wave = 0; I.S.placement = 0; for (int w = 0; w < QP_NW; w++) I.S.wave_rank[w] = w; }
+  __syncthreads();
+  const SpArrays SP = sp_arrays(V, b, slot, V.Dg + (size_t)slot * V.nfac);
+  switch (op) {
+    case QP_OP_LDLCHOL: sp_factor(V, b, n, SP, false, qp_prox(st, I.s) != 0, I.s.gamma); break;
+    case QP_OP_LDLCHOL_QATSA: sp_factor(V, b, n, SP, true, qp_prox(st, I.s) != 0, I.s.gamma); break;
+    case QP_OP_UPDATE_ENTER: sp_updown(V, b, n, SP, a.enter(), I.s.nb_enter, a.leave(), 0); break;
+    case QP_OP_DOWNDATE_LEAVE: sp_updown(V, b, n, SP, a.enter(), 0, a.leave(), I.s.nb_leave); break;
+    case QP_OP_UPDATE_SIGMA: {
+      const int nchg = I.s.nb_sigma_changed;
+      dev_ldlupdate_sigma_scale(a, nchg);
+      sp_updown(V, b, n, SP, a.enter(), nchg, a.leave(), 0);
+      dev_update_sigma_post(a, I, nchg);
+      break;
+    }
+    case QP_OP_SOLVE:
+      for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
+      __syncthreads();
+      sp_solve(n, SP, a.d());
+      break;
+    default: break;
+  }
+  __syncthreads();
+  if (tid == 0) V.sc[b] = I.s;
+}
+
 /* y = Op x for a caller-owned operator given by its compressed rows (boundary mat_vec) */
 __global__ __launch_bounds__(QP_T) void k_spmv_generic(int nrows, const int *ptr, const int *idx, const double *val, const double *x, double *y) {
   spmv_rows<8>(nrows, ptr, idx, val, x, [&](int r, double s) { y[r] = s; });

@@ -205,7 +205,7 @@ def test_sparse_factor_refuses_what_it_does_not_cover(ctx):
     try:
         bt = QpalmBatch(ctx, [p], ctx.default_settings(**ST))
         with pytest.raises(Exception):
-            bt.factor(0)                      # the single operations of solver_interface.h work on the dense panel
+            bt.factor(0)                      # reading the factor back as a dense panel works on the dense panel only
         bt.close()
         # KKT mode keeps the dense factor even when the sparse one is asked for (dual termination no longer does: round 6, next test)
         for kw in (dict(factorization_method=0),):
@@ -255,6 +255,83 @@ def test_sparse_factor_with_dual_termination_and_sigma_path_updates(ctx, kind, n
             assert int(bt.info(0).status_val) == o2.status_val == 2 and int(bt.info(0).iter) == int(o2.info.iter), (lim, bt.info(0).status_val, o2.status_val)   # DUAL_TERMINATED
             assert abs(bt.info(0).dual_objective - o2.info.dual_objective) <= 1e-8 * max(1.0, abs(o2.info.dual_objective))
             bt.close()
+    finally:
+        ctx.set_option("sparse_factor", -1)
+        ctx.set_option("sparse_ordering", -1)
+
+
+def test_sparse_factor_single_operations_of_the_boundary(ctx):
+    """Round 6: ldlcholQAtsigmaA, ldlupdate_entering / ldldowndate_leaving, ldlupdate_sigma_changed and ldlsolveLD_neg_dphi of solver_interface.h
+    on a batch that keeps the SPARSE factor (refused through round 5), each against the same operation of the oracle in its sparse-storage mode on
+    the same state.  The sparse factor cannot be read back entry by entry, so every step is checked through a solve with a fixed right-hand side --
+    and the updated factor against a fresh factorisation of the new active set (an oracle-free property)."""
+    import ctypes as C
+    n = 96
+    p = sparse_qp(n, "blocks", seed=6)
+    m = p.m
+    ctx.set_option("sparse_factor", 1)
+    ctx.set_option("sparse_ordering", 0)
+    try:
+        bt = QpalmBatch(ctx, [p], ctx.default_settings(**ST))
+        assert bt.sparse_info(0)[0] > 0
+        o = ob.OracleQP(*p.args(), settings=ob.default_settings(**dict(ST, max_iter=5)))
+        o.set_scalar("sparse_mode", 1)
+        o.solve()
+        bt.iterate(5)
+        assert rel(bt.vec("x"), o.vec("x")) <= 1e-9
+        L = ob.lib()
+        ln = ob.c_int(0)
+        rhs = np.random.default_rng(3).standard_normal(n)
+
+        def solve_both():
+            o.vec("dphi", copy=False)[:] = rhs
+            bt.set_vec("dphi", rhs)
+            L.oq_ldlsolveLD_neg_dphi(o.w)
+            bt.op("ldlsolveLD_neg_dphi")
+            return bt.vec("d").copy(), o.vec("d").copy()
+        act = (np.arange(m) % 3 == 0).astype(np.int64)
+        pa = L.oq_get_ivec(o.w, b"active", C.byref(ln))
+        np.ctypeslib.as_array(pa, shape=(m,))[:] = act
+        bt.set_ivec("active", act)
+        L.oq_ldlcholQAtsigmaA(o.w)
+        bt.op("ldlcholQAtsigmaA")
+        dg, do = solve_both()
+        assert rel(dg, do) <= 1e-10
+        enter, leave = np.where(act == 0)[0][:9], np.where(act == 1)[0][3:10]
+        act_new = act.copy(); act_new[enter] = 1; act_new[leave] = 0
+        for name, lst in (("enter", enter), ("leave", leave)):
+            bt.set_ivec(name, lst)
+        np.ctypeslib.as_array(L.oq_get_ivec(o.w, b"active_old", C.byref(ln)), shape=(m,))[:] = act
+        np.ctypeslib.as_array(pa, shape=(m,))[:] = act_new
+        L.oq_set_entering_leaving_constraints(o.w)
+        L.oq_ldlupdate_entering_constraints(o.w)
+        L.oq_ldldowndate_leaving_constraints(o.w)
+        bt.set_scalar("nb_enter", len(enter)); bt.set_scalar("nb_leave", len(leave))
+        bt.op("ldlupdate_entering_constraints")
+        bt.op("ldldowndate_leaving_constraints")
+        dg, do = solve_both()
+        assert rel(dg, do) <= 1e-9
+        bt.set_ivec("active", act_new)                       # property: the updated factor = a fresh one of the new active set
+        bt.op("ldlcholQAtsigmaA")
+        dfresh, _ = solve_both()
+        assert rel(dg, dfresh) <= 1e-9
+        # ldlupdate_sigma_changed: five rows of the active set with grown penalties (At_scale = sqrt(mult_factor), the list in enter[])
+        L.oq_ldlcholQAtsigmaA(o.w)
+        changed = np.where(act_new == 1)[0][2:7]
+        scale = np.ones(m); scale[changed] = np.sqrt(1.0 + 50.0 * np.random.default_rng(4).random(5))
+        o.vec("At_scale", copy=False)[:] = scale
+        bt.set_vec("At_scale", scale)
+        np.ctypeslib.as_array(L.oq_get_ivec(o.w, b"enter", C.byref(ln)), shape=(m,))[:5] = changed
+        bt.set_ivec("enter", changed)
+        L.oq_set_scalar(o.w, b"nb_sigma_changed", 5.0)
+        bt.set_scalar("nb_sigma_changed", 5)
+        L.oq_ldlupdate_sigma_changed(o.w)
+        bt.op("ldlupdate_sigma_changed")
+        dg, do = solve_both()
+        assert rel(dg, do) <= 1e-9 and np.array_equal(bt.vec("At_scale"), o.vec("At_scale"))
+        with pytest.raises(Exception):
+            bt.factor(0)                                     # (the dense read-back of the factor stays refused)
+        bt.close()
     finally:
         ctx.set_option("sparse_factor", -1)
         ctx.set_option("sparse_ordering", -1)
