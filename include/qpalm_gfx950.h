@@ -146,8 +146,13 @@ void qpg_ctx_destroy(qpg_ctx *ctx);
  *   "sweep_ranks"           16 (default) or 32 ranks per update sweep (32: the multi-pass sweep, bit-identical factors, slower)
  *   "kkt_compact"           1 = FACTORIZE_KKT factorises the variables + ACTIVE constraints only and spreads the factor out on demand
  *   "place_panel_wave"      0 / 1 / 2: SIMD placement of the sweeps' panel wavefronts (0 = the hardware's own)
- *   "sequential_rank_sums"  -1 (default) = update sweeps of QPs whose factor can get near-singular (nonconvex; Q without a positive diagonal: LPs) sum
- *                           a column's pivot rank after rank, the reference's order; 1 = all QPs; 0 = none (prefix tree: faster chain)
+ *   "sequential_rank_sums"  how an update sweep sums a column's pivots.  -1 (default) = a prefix tree, and any column in which a pivot
+ *                           shrinks by 2^8 or more inside the sweep is summed again as the reference's running pivot (per-column guard); the running
+ *                           pivot in every column for QPs whose factor can get near-singular (nonconvex; Q without a positive diagonal: LPs).
+ *                           1 = the running pivot everywhere (-5 % on the benchmark); 0 = the unguarded tree (A/B runs only: loses eight digits on a
+ *                           downdate into a numerically singular matrix)
+ *   "queue_order"           1 (default) = a launch of more QPs than resident slots starts the members in descending order of the kernel time of
+ *                           their previous solve (the launch's tail is then made of short solves); 0 = index order.  Never changes a result.
  *   "sparse_factor", "sparse_ordering"   the sparse L D L' and its ordering (qpg_batch_sparse_info / qpg_batch_sparse_perm below)
  *   "coop", "coop_workgroups", "coop_updates", "coop_rank_threshold"   one large QP on many workgroups
  * Environment: QPALM_HOST_THREADS = host threads of qpg_batch_set_problems (default: hardware threads, at most 24). */

@@ -9,7 +9,7 @@ from qpalm_amd.problems import random_qp
 
 def cases(seed, count, n_lo=2, n_hi=70, force=None):
     """force: dict of settings that overrides the drawn ones (the draws are made all the same, so the stream stays aligned);
-    the pseudo-setting q_shift makes the Hessian indefinite (use with nonconvex=1), lp = 1 zeroes Q"""
+    the pseudo-setting q_shift makes the Hessian indefinite (use with nonconvex=1), lp = 1 zeroes Q, q_scale multiplies it"""
     rng = np.random.default_rng(int(seed))
     for it in range(count):
         n = int(rng.integers(n_lo, n_hi))
@@ -35,7 +35,9 @@ def cases(seed, count, n_lo=2, n_hi=70, force=None):
         if rng.random() < 0.3:
             warm = (rng.standard_normal(n), rng.standard_normal(m))
         if force:
-            st.update({k: v for k, v in force.items() if k not in ("q_shift", "lp")})
+            st.update({k: v for k, v in force.items() if k not in ("q_shift", "lp", "q_scale")})
+            if force.get("q_scale"):
+                p.Qx[:] = p.Qx * float(force["q_scale"])   # pseudo-setting q_scale: a positive definite but tiny Hessian (positive diagonal: not flagged at setup)
             if force.get("lp"):
                 p.Qx[:] = 0.0   # pseudo-setting lp = 1: a linear programme -- H = A' Sigma A + I / gamma, pivots down to 1 / gamma_max
             if force.get("q_shift"):
