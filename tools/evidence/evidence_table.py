@@ -7,7 +7,7 @@ import os
 import re
 import sys
 
-d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r05", "final")
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r06", "final")
 J = lambda f: json.load(open(os.path.join(d, f)))
 b = J("bench_default.json")
 r, st = b["roofline"], b["solve_stats"]
@@ -52,6 +52,21 @@ if "mpc160" in b:
         mm = b["mpc160"].get(k, {})
         if "value" in mm:
             print("default line, mpc160.%s: %.0f QP/s (%.2f ms per step, kernel %.2f)" % (k, mm["value"], mm["ms_per_step"], mm["kernel_ms_per_step"]))
+if "mpc160" in b:   # round 6: the roofline object of the config-3 lines
+    for k in ("schur", "kkt"):
+        rr = b["mpc160"].get(k, {}).get("roofline")
+        if rr:
+            print("default line, mpc160.%s roofline: needed %.3f GB per launch in %.2f ms = %.0f GB/s = frac %.3f; traffic %s = %s x needed; per QP KB: %s" % (
+                k, rr["algorithmic_bytes_per_launch"] * 1e-9, rr["kernel_ms"], rr["achieved"], rr["frac"],
+                ("%.3f GB" % (rr["traffic"] * 1e-9)) if rr["traffic"] else "null", ("%.2f" % rr["traffic_over_algorithmic"]) if rr["traffic"] else "null",
+                {kk: round(v / 1024, 1) for kk, v in rr["bytes_per_qp"].items()}))
+for v, what in ((-1, "guarded prefix tree (default)"), (0, "unguarded prefix tree"), (1, "running pivot in every column")):
+    f = "bench_rank_sums_%d.json" % v
+    if os.path.exists(os.path.join(d, f)):
+        x = J(f)
+        print("pivot sums, %-32s %.0f QP/s, frac %.4f, update %.2f ms per QP, hash %s, guard %s" % (what + ":", x["value"], x["roofline"]["frac"], x["solve_stats"]["phase_ms_per_qp"]["update"],
+              x["solve_stats"]["solution_sha256_16"], x["solve_stats"].get("pivot_guard")))
+print("pivot guard of the reported line: %s" % st.get("pivot_guard"))
 if os.path.exists(os.path.join(d, "bench_sweep_ranks_32.json")):
     s32 = J("bench_sweep_ranks_32.json")
     print("sweep_ranks 32: %.0f QP/s, frac %.3f, needed %.3f TB, sweeps per QP %.1f, hash %s (default: %s)" % (
@@ -64,4 +79,6 @@ if os.path.exists(os.path.join(d, "phase_traffic", "phase_traffic.json")):
         if k in pt:
             print("phase traffic %-8s read %.2f write %.2f MB per QP, moved / needed %.3f" % (k, pt[k]["read"], pt[k]["write"], pt[k]["moved_over_needed"]))
 print(opt("sload_coherence.txt"))
-print(open(os.path.join(d, "pytest_gpu.log")).read().strip().splitlines()[-1])
+log = open(os.path.join(d, "pytest_gpu.log")).read().strip().splitlines()
+print("\n".join(l for l in log if l.startswith(("fuzz campaigns", "  [hip]", "  fuzz total"))))
+print(log[-1])

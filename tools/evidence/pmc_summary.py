@@ -41,7 +41,7 @@ try:  # the bench line of the FETCH pass names the workload it ran
     batch, n, m, kernel = int(cfg["batch_per_gpu"]), int(cfg.get("n", n)), int(cfg.get("m", m)), cfg.get("kernel", kernel)
 except Exception:
     pass
-res = {"kernel": kernel, "command": ("python bench.py --workload mpc-160%s --steps 5 --no-cpu (batch %%d, n=%%d, m=%%d): mean of the warm-started launches" %% (" --kkt" if prefix == "mpck_" else "")) %% (batch, n, m)
+res = {"kernel": kernel, "command": ("python bench.py --workload mpc-160" + (" --kkt" if prefix == "mpck_" else "") + " --steps 5 --no-cpu (batch %d, n=%d, m=%d): mean of the warm-started launches" % (batch, n, m))
        if prefix else "python bench.py --steps 1 --warmup 0 --no-cpu (batch %d, n=%d, m=%d)" % (batch, n, m),
        "batch": batch, "n": n, "m": m, "source_sha256": source_sha256(), "lib_sha256": lib_sha256(),
        "FETCH_SIZE_KB_per_launch": fe, "WRITE_SIZE_KB_per_launch": wr, "launches_seen": [nf, nw],
