@@ -24,7 +24,7 @@ seed = int(pos[0]) if len(pos) > 0 else 0
 N = int(pos[1]) if len(pos) > 1 else 100
 NLO, NHI = (int(pos[3]), int(pos[4])) if len(pos) > 4 else (2, 70)   # range of n (m up to 1.7 n)
 sparse = int(force.pop("sparse", 0))
-for opt in ("small_workgroups", "linesearch_hbm", "coop", "coop_rank_threshold", "coop_updates"):   # engine options, not settings (the 128-thread instance; the tiled line-search sort with tiles of that many entries; coop mode and its one-launch sweep)
+for opt in ("small_workgroups", "linesearch_hbm", "coop", "coop_rank_threshold", "coop_updates", "sequential_rank_sums"):   # engine options, not settings (the 128-thread instance; the tiled line-search sort with tiles of that many entries; coop mode and its one-launch sweep)
     if opt in force:
         ctx.set_option(opt, int(force.pop(opt)))
 ordering = force.pop("ordering", None)   # with sparse=1: 0 natural, 1 nested dissection (default: the library's automatic choice)
