@@ -1,4 +1,4 @@
-"""one fuzz case under the three pivot-sum modes: python tools/evidence/r06_case.py <seed> <case> <n_lo> <n_hi> key=value ..."""
+"""one fuzz case under the three pivot-sum modes: python tools/evidence/fuzz_case_modes.py <seed> <case> <n_lo> <n_hi> key=value ..."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch; torch.cuda.init()
