@@ -84,18 +84,19 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """One line per randomised campaign that ran: cases, rule failures, and the accepted-but-not-exact cases by bucket (tests/fuzz_cases.py:
     judge_case) -- `rounding` = the reference's own source changes its outcome under the compiler's flags / a one-ulp perturbation / the
     trajectory criterion, `engine-form` = only the oracle variants restating the engine's recurrence move, `singular` = non-finite in the
-    engine and in a reference build.  Everything else matched the oracle in status, iteration count, x and y."""
+    engine and in a reference build, `conditioning` = x / y beyond the tolerance but within twice the spread of the reference's own builds.  Everything else
+    matched the oracle in status, iteration count, x and y."""
     if not os.path.exists(_FUZZ_FILE):
         return
     rows = [json.loads(ln) for ln in open(_FUZZ_FILE) if ln.strip()]
     if not rows:
         return
     tr = terminalreporter
-    tr.write_line("fuzz campaigns (cases / rule failures / accepted as: rounding, engine-form, singular):")
-    tot = [0, 0, 0, 0, 0]
+    tr.write_line("fuzz campaigns (cases / rule failures / accepted as: rounding, engine-form, singular, conditioning):")
+    tot = [0, 0, 0, 0, 0, 0]
     for r in rows:
         b = r["by_class"]
-        v = [r["total"], r["failed"], b.get("rounding", 0), b.get("engine-form", 0), b.get("singular", 0)]
+        v = [r["total"], r["failed"], b.get("rounding", 0), b.get("engine-form", 0), b.get("singular", 0), b.get("conditioning", 0)]
         tot = [a + c for a, c in zip(tot, v)]
-        tr.write_line("  [%s] %-34s %5d / %d / %d, %d, %d" % (r["backend"], r["campaign"], *v))
-    tr.write_line("  fuzz total: %d cases, %d rule failures, %d rounding-decided, %d engine-form, %d singular" % tuple(tot))
+        tr.write_line("  [%s] %-34s %5d / %d / %d, %d, %d, %d" % (r["backend"], r["campaign"], *v))
+    tr.write_line("  fuzz total: %d cases, %d rule failures, %d rounding-decided, %d engine-form, %d singular, %d ill-conditioned" % tuple(tot))

@@ -128,8 +128,9 @@ def oracle_variants():
     return _VARIANTS
 
 
-def oracle_outcomes(p, st, warm, nonfinite=None):
-    """{variant: (status, iter)} of the oracle variants on one case; nonfinite (a set, optional) collects the variants whose x or y is not finite"""
+def oracle_outcomes(p, st, warm, nonfinite=None, solutions=None):
+    """{variant: (status, iter)} of the oracle variants on one case; nonfinite (a set, optional) collects the variants whose x or y is not finite,
+    solutions (a dict, optional) their (x, y)"""
     import oracle.binding as ob
     out = {}
     for name, lib in oracle_variants().items():
@@ -140,8 +141,29 @@ def oracle_outcomes(p, st, warm, nonfinite=None):
         out[name] = (int(o.status_val), int(o.info.iter))
         if nonfinite is not None and not (np.all(np.isfinite(o.x)) and np.all(np.isfinite(o.y))):
             nonfinite.add(name)
+        if solutions is not None:
+            solutions[name] = (o.x.copy(), o.y.copy())
         o.cleanup()
     return out
+
+
+def reference_builds_spread(p, st, warm):
+    """(dx, dy): how far the x and y of the reference's own source move when it is compiled with fused multiply-adds or -Ofast (NOT the variants that
+    restate the engine's formulas), relative like rel(), on a case all of them solve -- the conditioning of the problem as the reference itself sees it"""
+    import oracle.binding as ob
+    o = ob.OracleQP(*p.args(), settings=ob.default_settings(**st))
+    if warm is not None:
+        o.warm_start(warm[0], warm[1])
+    o.solve()
+    x0, y0, s0 = o.x.copy(), o.y.copy(), int(o.status_val)
+    o.cleanup()
+    sol = {}
+    var = oracle_outcomes(p, st, warm, None, sol)
+    dx = dy = 0.0
+    for name in ("fma", "ofast"):
+        if var[name][0] == s0 and s0 in (1, 2):
+            dx, dy = max(dx, rel(sol[name][0], x0)), max(dy, rel(sol[name][1], y0))
+    return dx, dy
 
 
 ENGINE_FORM_VARIANTS = ("pivot", "pivot_plain")   # oracle variants that restate the ENGINE's form of the rank-update recurrence (OQ_PIVOT_ENGINE)
@@ -172,7 +194,8 @@ def judge_case(r, p, st, warm, ytol=1e-8, ctx=None):
     """The sharp form of "parity with the oracle" for one case.  Returns (ok, why, cls): cls is False for a case that matches the oracle outright,
     else the bucket the accepted case is counted in -- "rounding" (the reference's own source changes its outcome under the compiler's flags or a
     one-ulp perturbation of the data, or the trajectory criterion holds), "engine-form" (only the oracle variants that restate the ENGINE's form
-    of the rank-update recurrence move), "singular" (non-finite iterates in the engine AND in a reference build: H singular by construction).
+    of the rank-update recurrence move), "singular" (non-finite iterates in the engine AND in a reference build: H singular by construction), "conditioning" (equal status and count, x
+    or y beyond the tolerance but within twice what the reference's own source moves under -ffp-contract=fast / -Ofast: the solution is determined to kappa eps).
       * (status, iterations) equal to the plain oracle's: x within 1e-8, y within ytol of it (solved cases).
       * otherwise the case must be one whose count ROUNDING decides -- the oracle's own source, compiled with fused multiply-adds or
         -Ofast, does not reproduce the plain oracle's (status, iterations) either; or (noise_decided_branch) the two iteration paths
@@ -194,7 +217,13 @@ def judge_case(r, p, st, warm, ytol=1e-8, ctx=None):
         if r.get("nonfinite", (False, False)) == (True, False):
             return False, "same status and count, but the engine's iterate is NOT FINITE and the oracle's is", False
         if r["status"][1] in (1, 2) and not (r["dx"] <= 1e-8 and r["dy"] <= ytol):
-            return False, "same count, x / y differ: dx %.3e dy %.3e (y bound %.3e)" % (r["dx"], r["dy"], ytol), False
+            # Round 6 (campaign 721, Hessians of 1e-10): same status, same count, x apart by 1e-8 .. 2e-6 -- and the reference's OWN source moves its x by as
+            # much when it is compiled with fused multiply-adds or -Ofast.  The solution is determined to kappa eps, not to 1e-8: accepted in a bucket of its
+            # own iff the engine is no further from the plain oracle than TWICE the spread of the reference's builds (x and y each), else it fails as before.
+            sx, sy = reference_builds_spread(p, st, warm)
+            if r["dx"] <= max(1e-8, 2.0 * sx) and r["dy"] <= max(ytol, 2.0 * sy):
+                return True, "ill-conditioned: dx %.3e dy %.3e against %.3e / %.3e between the reference's own builds" % (r["dx"], r["dy"], sx, sy), "conditioning"
+            return False, "same count, x / y differ: dx %.3e dy %.3e (y bound %.3e; the reference's own builds spread %.3e / %.3e)" % (r["dx"], r["dy"], ytol, sx, sy), False
         return True, "", False
     nonfin = set()
     var = oracle_outcomes(p, st, warm, nonfin)

@@ -51,7 +51,7 @@ for it, p, st, warm, meta in cases(seed, N, NLO, NHI, force or None):
             soft += 1 if ok else 0
             if ok:
                 by[rounding if isinstance(rounding, str) else "rounding"] = by.get(rounding if isinstance(rounding, str) else "rounding", 0) + 1
-            print("FAIL" if not ok else {"rounding": "ROUNDING-DECIDED", "engine-form": "ENGINE-FORM", "singular": "SINGULAR"}.get(rounding, "ROUNDING-DECIDED"), "seed", seed, "case", it, meta, {k: st[k] for k in ("factorization_method", "sigma_init", "scaling", "proximal")},
+            print("FAIL" if not ok else {"rounding": "ROUNDING-DECIDED", "engine-form": "ENGINE-FORM", "singular": "SINGULAR", "conditioning": "ILL-CONDITIONED"}.get(rounding, "ROUNDING-DECIDED"), "seed", seed, "case", it, meta, {k: st[k] for k in ("factorization_method", "sigma_init", "scaling", "proximal")},
                   "status", r["status"], "iter", r["iter"], "x", r["dx"], "y", r["dy"], "|", why)
             sys.stdout.flush()
     except Exception as e:
