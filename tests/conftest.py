@@ -9,6 +9,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`: the kernels on the host emulator, every GPU thread a fiber) takes twenty minutes on one core and five on six:
+    when nobody asked for a process count and pytest-xdist is there, it runs on min(6, cores) workers.  The GPU suite (one device, one context)
+    stays in one process; QPALM_TEST_SERIAL=1 keeps the CPU suite there too."""
+    try:
+        import xdist  # noqa: F401
+    except ImportError:
+        return None
+    opt = config.option
+    if (getattr(opt, "markexpr", "") or "").replace(" ", "") != "notgpu" or getattr(opt, "numprocesses", None) is not None or os.environ.get("QPALM_TEST_SERIAL") == "1":
+        return None
+    if getattr(opt, "collectonly", False) or hasattr(config, "workerinput"):
+        return None
+    n = min(6, os.cpu_count() or 1)
+    if n >= 2:
+        opt.numprocesses = n
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # Same order as bench.py: torch initialises the HIP runtime first, the solver library joins it.
@@ -78,6 +98,16 @@ def pytest_sessionstart(session):
             os.remove(_FUZZ_FILE)
         except OSError:
             pass
+        if getattr(session.config.option, "numprocesses", None):
+            # the test-only libraries are built ONCE, here, before the workers start: several workers finding a stale emulator library used to
+            # rebuild it at the same time and load each other's half-written file
+            try:
+                from qpalm_amd import build
+                build.build_oracle()
+                build.build_emu()
+                build.build_host_emu()
+            except Exception as e:   # noqa: BLE001 -- the tests that need a library report the failure themselves
+                sys.stderr.write("conftest: pre-building the test libraries failed: %r\n" % (e,))
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
