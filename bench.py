@@ -287,7 +287,7 @@ def cpu_baseline(problems, settings_kw, workload, budget_s=20.0, sparse=False):
             "sample": "%d of the batch's %s QPs x %d pass(es), setup + solve timed as info.run_time does (eps 1e-6), %d pthreads (the fastest of the thread counts in threads_tried_qps) pulling QPs from a "
                       "shared counter (oracle/cpu_bench.c, no Python in the loop), oracle/qpalm_oracle.c (%s) "
                       "built -O3 -march=native; one QP alone on one core: %.4f s; %s"
-                      % (nsample, workload, passes, cores, "sparse-storage L D L', natural ordering, path updates" if sparse else "dense LDL', scalar rank-1 sweeps", t_probe,
+                      % (nsample, workload, passes, cores, "sparse-storage L D L', natural ordering, path updates" if sparse else "dense LDL', rank-1 sweeps applied 8 at a time per pass over L (bit-identical to one at a time)", t_probe,
                          "a system CHOLMOD is present (probe in cholmod_probe) but this figure is the restatement" if have else
                          "no system CHOLMOD on the box (probe in cholmod_probe), so this is the restatement, not CHOLMOD")}
 
