@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libqpalm_gfx950.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libqpalm_gfx950_emu.so")
-_SRCS = ["../host/qpalm_host.c", "../host/qpalm_qps.c", "qpalm_kkt.h", "qpalm_gfx950.hip", "qpalm_kernels.h", "qpalm_device.h", "qpalm_dense.h", "qpalm_iter.h", "qpalm_types.h",
+_SRCS = ["../host/qpalm_host.c", "../host/qpalm_qps.c", "qpalm_kkt.h", "qpalm_sparse.h", "qpalm_gfx950.hip", "qpalm_kernels.h", "qpalm_device.h", "qpalm_dense.h", "qpalm_iter.h", "qpalm_types.h",
          "qpalm_capi.inc"]
 
 

@@ -939,7 +939,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
         __syncthreads();
         if (st.enable_dual_termination) { /* qpalm.c:543-583 */
           double dobj;
-          if constexpr (SPARSE) { SpArrays SQ = sp_arrays(V, b, slot, DgQ); SQ.Lx = LQ; dobj = dev_dual_objective_sp(V, a, b, SQ, I); }
+          if constexpr (SPARSE) { SpArrays SQ = sp_arrays(V, b, slot, DgQ, lds); SQ.Lx = LQ; dobj = dev_dual_objective_sp(V, a, b, SQ, I); }
           else dobj = dev_dual_objective(V, a, b, LQ, DgQ, I, lds);
           if (tid == 0) I.s.dual_objective = dobj;
           __syncthreads();
@@ -1025,7 +1025,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       /* sparse factor (qpalm_sparse.h): rows entering / leaving the active set are rank-1 updates along their elimination-tree
        * paths where that pays, a refactorisation otherwise; changed penalties likewise (la == 4: ldlupdate_sigma_changed as path updates with the scaled
        * rows, dev_update_sigma_pre decides) */
-      const SpArrays SP = sp_arrays(V, b, slot, Dg);
+      const SpArrays SP = sp_arrays(V, b, slot, Dg, lds);
       if (la == 2 && !sp_update_pays(nchange, SP.nlev, n)) { la = 1; action = 1; } /* a chain-like tree: refactorising is cheaper than walking it per row */
       if (la == 2) sp_updown(V, b, n, SP, a.enter(), I.s.nb_enter, a.leave(), I.s.nb_leave);
       else if (la == 4) sp_updown(V, b, n, SP, a.enter(), n_sig, a.leave(), 0); /* ldlupdate_sigma_changed: the rows listed in enter[], scaled by dev_ldlupdate_sigma_scale */
@@ -1090,7 +1090,7 @@ QPN void dev_solve(const qpg_view &V, int b, int slot, int budget, int fresh, It
       /* ldlsolveLD_neg_dphi (solver_interface.c:505-519) */
       if constexpr (SPARSE) {
         for (int j = tid; j < n; j += QP_T) a.d()[j] = a.dphi()[j] * -1;
-        sp_solve(n, sp_arrays(V, b, slot, Dg), a.d());
+        sp_solve(n, sp_arrays(V, b, slot, Dg, lds), a.d());
       } else
       if (!V.kkt && !resume) {
         const bool fused = (RPT > 0) && !QP_NOFUSE && (action == 2) && !V.offload;

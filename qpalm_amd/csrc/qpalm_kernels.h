@@ -501,7 +501,7 @@ __global__ __launch_bounds__(QP_T) QP_OCCUPANCY void k_op_sparse(qpg_view V, int
   const int n = a.n, tid = threadIdx.x, slot = b;
   if (tid == 0) { I.s = V.sc[b]; I.S.panel_wave = 0; I.S.placement = 0; for (int w = 0; w < QP_NW; w++) I.S.wave_rank[w] = w; }
   __syncthreads();
-  const SpArrays SP = sp_arrays(V, b, slot, V.Dg + (size_t)slot * V.nfac);
+  const SpArrays SP = sp_arrays(V, b, slot, V.Dg + (size_t)slot * V.nfac, QP_DYN_LDS());
   switch (op) {
     case QP_OP_LDLCHOL: sp_factor(V, b, n, SP, false, qp_prox(st, I.s) != 0, I.s.gamma); break;
     case QP_OP_LDLCHOL_QATSA: sp_factor(V, b, n, SP, true, qp_prox(st, I.s) != 0, I.s.gamma); break;

@@ -29,14 +29,36 @@
 #ifndef QPALM_SPARSE_H
 #define QPALM_SPARSE_H
 
+#ifndef QP_SP_LDS_FACTOR
+#define QP_SP_LDS_FACTOR 1 /* (bisection builds: 0 compiles the LDS form of the factorisation / of the solves out) */
+#endif
+#ifndef QP_SP_LDS_SOLVE
+#define QP_SP_LDS_SOLVE 1
+#endif
+/* measured on the two sparse batch workloads (profiles/r06/sparse_lds/variants.txt, QP/s banded / blocks): the phases as real functions with
+ * local copies of the array pointers (QP_SP_LOCAL 1) 13277 / 15972 against 12409 / 14728 without; requesting the entries of the first batch
+ * of rows of A (QP_SP_PREFETCH 1) and of columns of L (2) before the accumulators are set up LOSES (10878 / 15141, 11250 / 15349 with batches
+ * of two): the registers it holds live spill under the 128-VGPR cap.  Round 5's forms (everything in HBM, inlined): 10324 / 14017. */
+#ifndef QP_SP_LOCAL
+#define QP_SP_LOCAL 1
+#endif
+#ifndef QP_SP_PREFETCH
+#define QP_SP_PREFETCH 0
+#endif
+#ifndef QP_SPB
+#define QP_SPB 4 /* contributing rows of A / columns of L whose entries the LDS form of sp_factor requests at once */
+#endif
 struct SpArrays { /* this QP's symbolic arrays + this slot's values and work vectors */
   const int *Lp, *Li, *Rp, *Rk, *Rpos, *levptr, *levcol;
   const int *perm, *AtiP, *QfiP, *first; /* the factor's numbering (P H P'): perm[new] = old; Ati and Qfi renumbered; every row of A's first column */
   int nlev;
   double *Lx, *Dg, *wv, *tmp;
+  char *lds;     /* the workgroup's dynamic LDS (nothing else lives there while a factor operation runs) */
+  int lds_bytes, lds_cap; /* lds_cap = context option "sparse_lds": 0 = the HBM forms below, 1 = the LDS forms where they fit, >= 2: a test's limit on the entries of a column the LDS form takes */
 };
-QPD SpArrays sp_arrays(const qpg_view &V, int b, int slot, double *Dg) {
+QPD SpArrays sp_arrays(const qpg_view &V, int b, int slot, double *Dg, char *lds) {
   SpArrays s;
+  s.lds = lds; s.lds_bytes = V.lds_bytes; s.lds_cap = V.sp_lds;
   s.Lp = V.sp_Lp + (size_t)b * (V.n + 1); s.Li = V.sp_Li + (size_t)b * V.sp_nnzL;
   s.Rp = V.sp_Rp + (size_t)b * (V.n + 1); s.Rk = V.sp_Rk + (size_t)b * V.sp_nnzL; s.Rpos = V.sp_Rpos + (size_t)b * V.sp_nnzL;
   s.levptr = V.sp_levptr + (size_t)b * (V.n + 1); s.levcol = V.sp_levcol + (size_t)b * V.n;
@@ -53,7 +75,7 @@ QPD bool sp_level_needs_barrier(const SpArrays &S, int lev) {
 }
 /* H = Q (+ A' Sigma_act A) (+ I / gamma) assembled column by column and factorised in the same pass (see the header).
  * with_AtSA = false, proximal = false: the second resident factor LD_Q of the dual objective (dev_solve, la == 7), into the value arrays the caller points S at. */
-QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, bool with_AtSA, bool proximal, double gamma) {
+QPNI void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S_, bool with_AtSA, bool proximal, double gamma) {
   /* a column per GROUP of lanes: the columns of a sparse factor are short (a band: half a dozen entries), so a wavefront takes gpw = 1, 2
    * or 4 columns of the level at a time (16 lanes each at 4) and a 512-thread workgroup up to 32 -- every step of a column is a chain of
    * dependent HBM round trips, the groups' chains overlap.  Loops run to the wavefront's longest trip count with the other groups
@@ -67,7 +89,28 @@ QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, boo
   const int *Qfp = V.Qfp + (size_t)b * (V.n + 1);
   const double *Qfx = V.Qfx + (size_t)b * V.nnzQf;
   const int *active = V.active + (size_t)b * V.m;
+#if QP_SP_LOCAL
+  const SpArrays S = S_; /* (a real function: the fields of S_ would be re-read from the caller's frame after every store) */
+  const int *Li = QP_UNIFORM_PTR(S.Li), *Lp = QP_UNIFORM_PTR(S.Lp), *Rp = QP_UNIFORM_PTR(S.Rp), *Rk = QP_UNIFORM_PTR(S.Rk), *Rpos = QP_UNIFORM_PTR(S.Rpos);
+  const int *AtiP = QP_UNIFORM_PTR(S.AtiP), *QfiP = QP_UNIFORM_PTR(S.QfiP);
+  double *Lx = QP_UNIFORM_PTR(S.Lx), *Dg = QP_UNIFORM_PTR(S.Dg);
+#else
+  const SpArrays &S = S_;
+  const int *Li = S.Li, *Lp = S.Lp, *Rp = S.Rp, *Rk = S.Rk, *Rpos = S.Rpos, *AtiP = S.AtiP, *QfiP = S.QfiP;
+  double *Lx = S.Lx, *Dg = S.Dg;
+#endif
   double *w = S.wv + (size_t)grp * n; /* this group's work vector: zero on entry, zero again when the column is done */
+  /* LDS form of a column (round 6): the column's accumulators live in the group's share of the dynamic LDS, indexed by POSITION in the
+   * column's pattern (0 = the diagonal, 1 + e - e0 = entry e); the pattern's row indices sit next to them and a contribution to row i
+   * finds its position by binary search there (rows ascending).  What a column costs is its chain of dependent HBM round trips: in the
+   * HBM form every contribution is a read-modify-write of the work vector (index -> value -> store, one after the other because two
+   * contributions may hit the same row); here the indices and values of QP_SPB contributing rows / columns are fetched at once and
+   * applied in order on LDS.  Per entry the same operations in the same order as the HBM form. */
+  const int cap_lds = (QP_SP_LDS_FACTOR && S.lds_cap) ? (((S.lds_bytes / ngrp) / 12) & ~1) : 0; /* entries per group: 8 B accumulator + 4 B row index */
+  const int cap = (S.lds_cap >= 2 && S.lds_cap < cap_lds) ? S.lds_cap : cap_lds; /* (cap_lds stays the stride) */
+  double QP_LDS_AS *wl = QP_LDS_ARG(double, S.lds) + (size_t)grp * cap_lds;
+  int QP_LDS_AS *ridx = (int QP_LDS_AS *)(QP_LDS_ARG(double, S.lds) + (size_t)ngrp * cap_lds) + (size_t)grp * cap_lds;
+  const int gbase = lane & ~(spg - 1);
   __syncthreads();
   for (int lev = 0; lev < S.nlev; lev++) {
     const int c0 = S.levptr[lev], c1 = S.levptr[lev + 1];
@@ -77,6 +120,158 @@ QPN void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S, boo
       const int j = on ? S.levcol[c] : 0;
       const int jo = on ? S.perm[j] : 0; /* column j of P H P' is column perm[j] of H; row indices through AtiP / QfiP */
       const int e0 = on ? S.Lp[j] : 0, e1 = on ? S.Lp[j + 1] : 0;
+      if (cap > 0 && wave_imax(e1 - e0 + 1) <= cap) {
+        const int len = e1 - e0;
+        auto posof = [&](const int i) QP_ALWAYS_INLINE { /* position of row i (>= j, in the pattern) among the accumulators */
+          if (i == j) return 0;
+          int lo = 0, hi = len;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (ridx[mid] < i) lo = mid + 1; else hi = mid; }
+          return lo + 1;
+        };
+        /* ---- everything the column reads that does not depend on its own sums is requested up front, level by level of the index
+         * chains (pointers -> first chunk of indices -> what those point at -> the entries of the first QP_SPB rows of A and columns
+         * of L), so that the column pays ~7 dependent round trips instead of one or two per contributing row / column ---- */
+        const bool wA = on && with_AtSA;
+        const int p0 = wA ? Ap[jo] : 0, p1 = wA ? Ap[jo + 1] : 0;
+        const int k0 = on ? Qfp[jo] : 0, k1 = on ? Qfp[jo + 1] : 0;
+        const int r0 = on ? Rp[j] : 0, r1 = on ? Rp[j + 1] : 0;
+        const int f_li = (e0 + gl < e1) ? Li[e0 + gl] : 0;
+        int f_t = -1, f_ainv = 0, f_qi = -1, f_k = -1, f_tpos = 0;
+        double f_qx = 0.0;
+        if (p0 + gl < p1) { f_t = Ai[p0 + gl]; f_ainv = Ainv[p0 + gl]; }
+        if (k0 + gl < k1) { f_qi = QfiP[k0 + gl]; f_qx = Qfx[k0 + gl]; }
+        if (r0 + gl < r1) { f_k = Rk[r0 + gl]; f_tpos = Rpos[r0 + gl]; }
+        int f_tq0 = 0, f_tq1 = 0, f_tk1 = 0;
+        double f_tv = 0.0, f_tl = 0.0, f_td = 0.0;
+        if (f_t >= 0) { const int act = active[f_t]; const double v = Atss[f_ainv]; const int q0 = Atp[f_t], q1 = Atp[f_t + 1]; if (act) { f_tv = v; f_tq0 = q0; f_tq1 = q1; } }
+        if (f_k >= 0) { f_tl = Lx[f_tpos]; f_td = Dg[f_k]; f_tk1 = Lp[f_k + 1]; }
+        const int np = wave_imax(p1 - p0), nr = wave_imax(r1 - r0);
+        /* a batch of QP_SPB rows of A: their entries, one per lane, requested together (load), applied in order (apply) */
+        int a_iv[QP_SPB], a_q0[QP_SPB], a_q1[QP_SPB];
+        double a_av[QP_SPB], a_vj[QP_SPB];
+        bool a_over = false;
+        auto A_load = [&](const int s0, const int cnt, const double tv, const int tq0, const int tq1) QP_ALWAYS_INLINE {
+          int longest = 0;
+#pragma unroll
+          for (int u = 0; u < QP_SPB; u++) {
+            const int src = gbase + ((s0 + u) & (spg - 1));
+            const bool has = s0 + u < cnt;
+            a_vj[u] = __shfl(tv, src);
+            const int sq0 = __shfl(tq0, src), sq1 = __shfl(tq1, src); /* (every lane takes part in a shuffle) */
+            a_q0[u] = has ? sq0 : 0; a_q1[u] = has ? sq1 : 0;
+            const int q = a_q0[u] + gl;
+            const bool valid = q < a_q1[u];
+            a_iv[u] = valid ? AtiP[q] : -1;
+            a_av[u] = valid ? Atss[q] : 0.0;
+            longest = (a_q1[u] - a_q0[u] > longest) ? (a_q1[u] - a_q0[u]) : longest;
+          }
+          a_over = wave_imax(longest) > spg; /* a row of A with more entries than the group has lanes: the rest in a loop */
+        };
+        auto A_apply = [&]() QP_ALWAYS_INLINE {
+#pragma unroll
+          for (int u = 0; u < QP_SPB; u++) {
+            if (a_iv[u] >= j) { const int p = posof(a_iv[u]); wl[p] += a_av[u] * a_vj[u]; }
+            if (a_over)
+              for (int q = a_q0[u] + gl + spg; q < a_q1[u]; q += spg) {
+                const int i = AtiP[q];
+                if (i >= j) { const int p = posof(i); wl[p] += Atss[q] * a_vj[u]; }
+              }
+            QP_WAVE_SYNC();
+          }
+        };
+        /* a batch of QP_SPB columns k of row j's structure: their entries below row j */
+        int l_iv[QP_SPB], l_ev[QP_SPB], l_k1[QP_SPB];
+        double l_lx[QP_SPB], l_mk[QP_SPB], l_lj[QP_SPB];
+        bool l_has[QP_SPB], l_over = false;
+        auto L_load = [&](const int rb, const int s0, const int cnt, const double tl, const double td, const int tpos, const int tk1) QP_ALWAYS_INLINE {
+          int longest = 0;
+#pragma unroll
+          for (int u = 0; u < QP_SPB; u++) {
+            const int src = gbase + ((s0 + u) & (spg - 1));
+            l_has[u] = (s0 + u < cnt) && (r0 + rb + s0 + u < r1);
+            l_lj[u] = __shfl(tl, src);
+            l_mk[u] = l_lj[u] * __shfl(td, src);
+            const int pos = __shfl(tpos, src);
+            const int sk1 = __shfl(tk1, src);
+            l_k1[u] = l_has[u] ? sk1 : 0;
+            l_ev[u] = pos + 1 + gl;
+            const bool valid = l_has[u] && l_ev[u] < l_k1[u];
+            l_iv[u] = valid ? Li[l_ev[u]] : -1;
+            l_lx[u] = valid ? Lx[l_ev[u]] : 0.0;
+            const int below = l_has[u] ? (l_k1[u] - pos - 1) : 0;
+            longest = (below > longest) ? below : longest;
+          }
+          l_over = wave_imax(longest) > spg;
+        };
+        auto L_apply = [&]() QP_ALWAYS_INLINE {
+#pragma unroll
+          for (int u = 0; u < QP_SPB; u++) {
+            if (l_has[u] && gl == 0) wl[0] = QP_FMA(-l_lj[u], l_mk[u], wl[0]);
+            if (l_iv[u] >= 0) { const int p = posof(l_iv[u]); wl[p] = QP_FMA(-l_lx[u], l_mk[u], wl[p]); }
+            if (l_over)
+              for (int e = l_ev[u] + spg; e < l_k1[u]; e += spg) {
+                const int p = posof(Li[e]);
+                wl[p] = QP_FMA(-Lx[e], l_mk[u], wl[p]);
+              }
+            QP_WAVE_SYNC();
+          }
+        };
+        const int cntA0 = (np < spg) ? np : spg, cntL0 = (nr < spg) ? nr : spg;
+        if (QP_SP_PREFETCH >= 1 && np > 0) A_load(0, cntA0, f_tv, f_tq0, f_tq1);
+        if (QP_SP_PREFETCH >= 2 && nr > 0) L_load(0, 0, cntL0, f_tl, f_td, f_tpos, f_tk1);
+        /* ---- the pattern's row indices and zeroed accumulators ---- */
+        for (int e = e0 + gl; e < e1; e += spg) { ridx[e - e0] = (e == e0 + gl) ? f_li : Li[e]; wl[e - e0 + 1] = 0.0; }
+        if (on && gl == 0) wl[0] = 0.0;
+        QP_WAVE_SYNC();
+        /* ---- A' Sigma A, column j: active rows t ascending ---- */
+        for (int pb = 0; pb < np; pb += spg) {
+          int tq0 = f_tq0, tq1 = f_tq1;
+          double tv = f_tv;
+          if (pb > 0) {
+            const int pm = p0 + pb + gl;
+            tq0 = 0; tq1 = 0; tv = 0.0;
+            if (pm < p1) {
+              const int t = Ai[pm];
+              if (active[t]) { tv = Atss[Ainv[pm]]; tq0 = Atp[t]; tq1 = Atp[t + 1]; }
+            }
+          }
+          const int cnt = (np - pb < spg) ? (np - pb) : spg;
+          for (int s0 = 0; s0 < cnt; s0 += QP_SPB) {
+            if (QP_SP_PREFETCH < 1 || pb > 0 || s0 > 0) A_load(s0, cnt, tv, tq0, tq1);
+            A_apply();
+          }
+        }
+        /* ---- + Q(:, j), + 1 / gamma ---- */
+        if (f_qi >= j) { const int p = posof(f_qi); wl[p] = f_qx + wl[p]; }
+        for (int k = k0 + gl + spg; k < k1; k += spg) {
+          const int i = QfiP[k];
+          if (i >= j) { const int p = posof(i); wl[p] = Qfx[k] + wl[p]; }
+        }
+        QP_WAVE_SYNC();
+        if (on && proximal && gl == 0) wl[0] += 1.0 / gamma;
+        QP_WAVE_SYNC();
+        /* ---- left-looking updates: every column k < j with l_jk != 0, ascending ---- */
+        for (int rb = 0; rb < nr; rb += spg) {
+          int tpos = f_tpos, tk1 = f_tk1;
+          double tl = f_tl, td = f_td;
+          if (rb > 0) {
+            const int rm = r0 + rb + gl;
+            tpos = 0; tk1 = 0; tl = 0.0; td = 0.0;
+            if (rm < r1) { const int k = Rk[rm]; tpos = Rpos[rm]; tl = Lx[tpos]; td = Dg[k]; tk1 = Lp[k + 1]; }
+          }
+          const int cnt = (nr - rb < spg) ? (nr - rb) : spg;
+          for (int s0 = 0; s0 < cnt; s0 += QP_SPB) {
+            if (QP_SP_PREFETCH < 2 || rb > 0 || s0 > 0) L_load(rb, s0, cnt, tl, td, tpos, tk1);
+            L_apply();
+          }
+        }
+        /* ---- pivot and column ---- */
+        const double dj = on ? wl[0] : 1.0;
+        for (int e = e0 + gl; e < e1; e += spg) Lx[e] = wl[e - e0 + 1] / dj;
+        if (on && gl == 0) Dg[j] = dj;
+        QP_WAVE_SYNC();
+        continue;
+      }
       /* ---- A' Sigma A, column j: active rows t ascending, lanes over the entries of row t (distinct columns i: no conflicts) ---- */
       if (with_AtSA) {
         /* what a row costs is its chain of dependent round trips (row index -> active flag, value, row pointers -> entries), so the
@@ -212,7 +407,12 @@ QPN double sp_gershgorin(const qpg_view &V, int b, const int n, const SpArrays &
  * w_i <- w_i - w_j l_ij, l_ij <- l_ij - gamma w_i.  Columns off the path are not touched.  Cost: one chain step (a few dependent HBM
  * round trips) per path column -- cheap on bushy trees (block structure), hopeless on a chain (band matrix): sp_update_pays decides. */
 /* (sp_update_pays: qpalm_iter.h, in front of dev_update_sigma_pre, which applies the same rule to changed penalties) */
-QPN void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S, const int *up, int n_up, const int *dn, int n_dn) {
+QPNI void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S_, const int *up, int n_up, const int *dn, int n_dn) {
+#if QP_SP_LOCAL
+  const SpArrays S = S_;
+#else
+  const SpArrays &S = S_;
+#endif
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1);
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
@@ -252,17 +452,29 @@ QPN void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S, con
   __syncthreads();
 }
 
-/* x <- (L D L')^-1 x, in place in HBM */
-QPN void sp_solve(const int n, const SpArrays &S, double *xo) {
-  double *x = S.tmp; /* P b; the result goes back as P' x */
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += QP_T) x[j] = xo[S.perm[j]];
-  __syncthreads();
+/* x <- (L D L')^-1 x.  The permuted right-hand side lives in LDS where it fits (xs: the gathers x[k] of a row / column are LDS reads and
+ * the entries of L are requested QP_SPU at a time; the subtractions stay in the row's / column's order), else in HBM (S.tmp). */
+#ifndef QP_SPU
+#define QP_SPU 4
+#endif
+template <class XP> QPD void sp_solve_levels(const int n, const SpArrays &S, XP x) {
   for (int lev = 0; lev < S.nlev; lev++) { /* forward: a row needs the rows of its structure, which sit in earlier levels */
     for (int c = S.levptr[lev] + (int)threadIdx.x; c < S.levptr[lev + 1]; c += QP_T) {
       const int j = S.levcol[c];
       double v = x[j];
-      for (int r = S.Rp[j]; r < S.Rp[j + 1]; r++) v -= S.Lx[S.Rpos[r]] * x[S.Rk[r]];
+      int r = S.Rp[j];
+      const int r1 = S.Rp[j + 1];
+      for (; r + QP_SPU <= r1; r += QP_SPU) {
+        int pp[QP_SPU], kk[QP_SPU];
+        double lv[QP_SPU];
+#pragma unroll
+        for (int u = 0; u < QP_SPU; u++) { pp[u] = S.Rpos[r + u]; kk[u] = S.Rk[r + u]; }
+#pragma unroll
+        for (int u = 0; u < QP_SPU; u++) lv[u] = S.Lx[pp[u]];
+#pragma unroll
+        for (int u = 0; u < QP_SPU; u++) v -= lv[u] * x[kk[u]];
+      }
+      for (; r < r1; r++) v -= S.Lx[S.Rpos[r]] * x[S.Rk[r]];
       x[j] = v;
     }
     if (sp_level_needs_barrier(S, lev)) __syncthreads();
@@ -274,13 +486,44 @@ QPN void sp_solve(const int n, const SpArrays &S, double *xo) {
     for (int c = S.levptr[lev] + (int)threadIdx.x; c < S.levptr[lev + 1]; c += QP_T) {
       const int j = S.levcol[c];
       double v = x[j];
-      for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) v -= S.Lx[e] * x[S.Li[e]];
+      int e = S.Lp[j];
+      const int e1 = S.Lp[j + 1];
+      for (; e + QP_SPU <= e1; e += QP_SPU) {
+        int ii[QP_SPU];
+        double lv[QP_SPU];
+#pragma unroll
+        for (int u = 0; u < QP_SPU; u++) { ii[u] = S.Li[e + u]; lv[u] = S.Lx[e + u]; }
+#pragma unroll
+        for (int u = 0; u < QP_SPU; u++) v -= lv[u] * x[ii[u]];
+      }
+      for (; e < e1; e++) v -= S.Lx[e] * x[S.Li[e]];
       x[j] = v;
     }
     if (lev == 0 || sp_level_needs_barrier(S, lev - 1)) __syncthreads();
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < n; j += QP_T) xo[S.perm[j]] = x[j];
+}
+QPNI void sp_solve(const int n, const SpArrays &S_, double *xo) {
+#if QP_SP_LOCAL
+  const SpArrays S = S_;
+#else
+  const SpArrays &S = S_;
+#endif
+  const bool in_lds = QP_SP_LDS_SOLVE && S.lds_cap && (size_t)n * sizeof(double) <= (size_t)S.lds_bytes;
+  __syncthreads();
+  if (in_lds) {
+    double QP_LDS_AS *x = QP_LDS_ARG(double, S.lds);
+    for (int j = threadIdx.x; j < n; j += QP_T) x[j] = xo[S.perm[j]]; /* P b; the result goes back as P' x */
+    __syncthreads();
+    sp_solve_levels(n, S, x);
+    for (int j = threadIdx.x; j < n; j += QP_T) xo[S.perm[j]] = x[j];
+  } else {
+    double *x = S.tmp;
+    for (int j = threadIdx.x; j < n; j += QP_T) x[j] = xo[S.perm[j]];
+    __syncthreads();
+    sp_solve_levels(n, S, x);
+    for (int j = threadIdx.x; j < n; j += QP_T) xo[S.perm[j]] = x[j];
+  }
   __syncthreads();
 }
 

@@ -529,3 +529,41 @@ def test_sparse_factor_nonconvex_warm_start_updates_and_queue(ctx):
     finally:
         ctx.set_option("max_slots", 512)
         ctx.set_option("sparse_factor", -1)
+
+
+def test_sparse_lds_forms_are_bit_identical_to_the_hbm_forms(ctx):
+    """Round 6: the factorisation accumulates a column in LDS (positions found by binary search in the column's pattern, the entries of four
+    contributing rows / columns requested at once) and the solves keep the right-hand side in LDS: per entry the same operations in the same
+    order as the forms that work on vectors in HBM (context option "sparse_lds" = 0), so the iterates are equal BIT FOR BIT -- with rows of A
+    and columns of L longer than a group of lanes (a 40-column row of A: a 40-clique), under both orderings, and with the LDS form limited to
+    columns of at most six entries ("sparse_lds" = 6: the longer columns of the same factorisation take the HBM form)."""
+    rng = np.random.default_rng(5)
+    p = sparse_qp(60, "banded", seed=8)
+    A = sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n)).tolil()
+    A[3, rng.choice(p.n, size=40, replace=False)] = 0.1 * rng.standard_normal(40)
+    A = sp.csc_matrix(A); A.sort_indices()
+    p1 = type(p)(p.n, p.m, p.Qp, p.Qi, p.Qx, A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64), p.q, p.bmin, p.bmax)
+    cases = [(p1, 0, 6), (p1, 1, 6), (sparse_qp(48, "blocks", seed=2), 0, 0), (sparse_qp(40, "arrow", seed=3), 1, 0), (random_qp(40, 80, seed=7, density_A=0.05, density_M=0.04), 0, 0)]
+    ctx.set_option("sparse_factor", 1)
+    try:
+        for q, ordering, iters in cases:
+            ctx.set_option("sparse_ordering", ordering)
+            res = {}
+            for mode in (0, 1, 6):
+                ctx.set_option("sparse_lds", mode)
+                bt = QpalmBatch(ctx, [q], ctx.default_settings(**dict(ST, enable_dual_termination=1)))
+                if iters:
+                    bt.iterate(iters)
+                    res[mode] = (bt.vec("x").copy(), bt.vec("y").copy(), 0)
+                else:
+                    bt.solve()
+                    x, y = bt.solution()
+                    assert int(bt.info(0).status_val) == 1
+                    res[mode] = (x[0].copy(), y[0].copy(), int(bt.info(0).iter))
+                bt.close()
+            for mode in (1, 6):
+                assert res[mode][2] == res[0][2] and np.array_equal(res[mode][0], res[0][0]) and np.array_equal(res[mode][1], res[0][1]), (ordering, mode)
+    finally:
+        ctx.set_option("sparse_factor", -1)
+        ctx.set_option("sparse_ordering", -1)
+        ctx.set_option("sparse_lds", 1)
