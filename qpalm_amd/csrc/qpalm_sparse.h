@@ -416,38 +416,53 @@ QPNI void sp_updown(const qpg_view &V, int b, const int n, const SpArrays &S_, c
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int *Atp = V.Atp + (size_t)b * (V.m + 1);
   const double *Atss = V.Atss + (size_t)b * V.nnzA;
-  double *w = S.wv; /* wavefront 0's work vector */
-  __syncthreads();
-  if (wid == 0) {
+  const int *Lp = QP_UNIFORM_PTR(S.Lp), *Li = QP_UNIFORM_PTR(S.Li), *AtiP = QP_UNIFORM_PTR(S.AtiP);
+  double *Lx = QP_UNIFORM_PTR(S.Lx), *Dg = QP_UNIFORM_PTR(S.Dg);
+  /* the work vector in LDS where n doubles fit (round 6): w_j and the w_i of a path column are LDS accesses, so a column costs two dependent
+   * HBM round trips (its extent and pivot; its entries) instead of four -- the next column of the path comes from lane 0's first entry */
+  const bool in_lds = QP_SP_LDS_SOLVE && S.lds_cap && (size_t)n * sizeof(double) <= (size_t)S.lds_bytes;
+  auto walk = [&](auto w) QP_ALWAYS_INLINE {
     for (int c = 0; c < n_up + n_dn; c++) {
       const bool update = c < n_up;
       const int t = update ? up[c] : dn[c - n_up];
       const int q0 = Atp[t], q1 = Atp[t + 1];
       if (q1 <= q0) continue;
-      for (int q = q0 + lane; q < q1; q += 64) w[S.AtiP[q]] = Atss[q];
+      for (int q = q0 + lane; q < q1; q += 64) w[AtiP[q]] = Atss[q];
       QP_WAVE_SYNC();
       double alpha = 1.0;
       int j = S.first[t]; /* the row's first column in the factor's numbering: the path starts there */
       while (j >= 0) {
-        const int e0 = S.Lp[j], e1 = S.Lp[j + 1];
+        const int e0 = Lp[j], e1 = Lp[j + 1];
         const double wj = w[j];
-        double dj = S.Dg[j], a, gam;
+        double dj = Dg[j], a, gam;
         QP_WAVE_SYNC(); /* every lane has read w_j and d_j before lane 0 overwrites them below */
         if (update) { a = alpha + (wj * wj) / dj; dj *= a; gam = -wj / dj; }
         else        { a = alpha - (wj * wj) / dj; dj *= a; gam =  wj / dj; }
         dj /= alpha;
         alpha = a;
+        int ifirst = -1; /* lane 0: the first row of the column's pattern = the parent = the next column of the path */
         for (int e = e0 + lane; e < e1; e += 64) {
-          const int i = S.Li[e];
-          const double wi = w[i] - wj * S.Lx[e];
+          const int i = Li[e];
+          const double lx = Lx[e];
+          const double wi = w[i] - wj * lx;
           w[i] = wi;
-          S.Lx[e] = S.Lx[e] - gam * wi;
+          Lx[e] = lx - gam * wi;
+          if (e == e0) ifirst = i;
         }
-        if (lane == 0) { S.Dg[j] = dj; w[j] = 0.0; }
+        if (lane == 0) { Dg[j] = dj; w[j] = 0.0; }
         QP_WAVE_SYNC();
-        j = (e1 > e0) ? S.Li[e0] : -1;
+        j = __shfl(ifirst, 0);
       }
     }
+  };
+  __syncthreads();
+  if (in_lds) {
+    double QP_LDS_AS *w = QP_LDS_ARG(double, S.lds);
+    for (int i = threadIdx.x; i < n; i += QP_T) w[i] = 0.0; /* (the walks leave it zero again) */
+    __syncthreads();
+    if (wid == 0) walk(w);
+  } else {
+    if (wid == 0) walk(S.wv); /* wavefront 0's work vector in HBM: zero outside of use */
   }
   __syncthreads();
 }
