@@ -154,6 +154,9 @@ void qpg_ctx_destroy(qpg_ctx *ctx);
  *   "queue_order"           1 (default) = a launch of more QPs than resident slots starts the members in descending order of the kernel time of
  *                           their previous solve (the launch's tail is then made of short solves); 0 = index order.  Never changes a result.
  *   "sparse_factor", "sparse_ordering"   the sparse L D L' and its ordering (qpg_batch_sparse_info / qpg_batch_sparse_perm below)
+ *   "sparse_lds"            1 (default) = the sparse factorisation accumulates a column, the sparse solves keep the right-hand side and the path
+ *                           updates their work vector in LDS where they fit; 0 = the forms on vectors in HBM (same iterates bit for bit: A/B and
+ *                           tests); >= 2 = LDS only for columns of at most that many entries (tests)
  *   "coop", "coop_workgroups", "coop_updates", "coop_rank_threshold"   one large QP on many workgroups
  * Environment: QPALM_HOST_THREADS = host threads of qpg_batch_set_problems (default: hardware threads, at most 24). */
 int  qpg_ctx_set_option(qpg_ctx *ctx, const char *name, qpg_int value);
