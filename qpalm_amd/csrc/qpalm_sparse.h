@@ -107,7 +107,12 @@ QPNI void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S_, b
    * contributions may hit the same row); here the indices and values of QP_SPB contributing rows / columns are fetched at once and
    * applied in order on LDS.  Per entry the same operations in the same order as the HBM form. */
   const int cap_lds = (QP_SP_LDS_FACTOR && S.lds_cap) ? (((S.lds_bytes / ngrp) / 12) & ~1) : 0; /* entries per group: 8 B accumulator + 4 B row index */
-  const int cap = (S.lds_cap >= 2 && S.lds_cap < cap_lds) ? S.lds_cap : cap_lds; /* (cap_lds stays the stride) */
+  /* the LDS form pays while the entries of a contributing column fit one or two passes of the group (a position costs a binary search on LDS,
+   * per pass; the HBM form's passes are independent read-modify-writes): by default columns of at most 2 spg entries take it, longer ones --
+   * near-dense factors -- the HBM form (measured: campaign S at n = 257..420 with near-dense L ran 5 x slower with every column in LDS).
+   * "sparse_lds" >= 2 sets the limit (tests; cap_lds stays the stride) */
+  const int cap_want = (S.lds_cap >= 2) ? S.lds_cap : 2 * spg;
+  const int cap = (cap_want < cap_lds) ? cap_want : cap_lds;
   double QP_LDS_AS *wl = QP_LDS_ARG(double, S.lds) + (size_t)grp * cap_lds;
   int QP_LDS_AS *ridx = (int QP_LDS_AS *)(QP_LDS_ARG(double, S.lds) + (size_t)ngrp * cap_lds) + (size_t)grp * cap_lds;
   const int gbase = lane & ~(spg - 1);

@@ -535,8 +535,9 @@ def test_sparse_lds_forms_are_bit_identical_to_the_hbm_forms(ctx):
     """Round 6: the factorisation accumulates a column in LDS (positions found by binary search in the column's pattern, the entries of four
     contributing rows / columns requested at once) and the solves keep the right-hand side in LDS: per entry the same operations in the same
     order as the forms that work on vectors in HBM (context option "sparse_lds" = 0), so the iterates are equal BIT FOR BIT -- with rows of A
-    and columns of L longer than a group of lanes (a 40-column row of A: a 40-clique), under both orderings, and with the LDS form limited to
-    columns of at most six entries ("sparse_lds" = 6: the longer columns of the same factorisation take the HBM form)."""
+    and columns of L longer than a group of lanes (a 40-column row of A: a 40-clique), under both orderings, with the LDS form limited to
+    columns of at most six entries ("sparse_lds" = 6: the longer columns of the same factorisation take the HBM form; the default limit is two
+    passes of a group, 32 entries) and with columns of up to 200 entries in LDS ("sparse_lds" = 200: the 40-clique's columns)."""
     rng = np.random.default_rng(5)
     p = sparse_qp(60, "banded", seed=8)
     A = sp.csc_matrix((p.Ax, p.Ai, p.Ap), shape=(p.m, p.n)).tolil()
@@ -549,7 +550,7 @@ def test_sparse_lds_forms_are_bit_identical_to_the_hbm_forms(ctx):
         for q, ordering, iters in cases:
             ctx.set_option("sparse_ordering", ordering)
             res = {}
-            for mode in (0, 1, 6):
+            for mode in (0, 1, 6, 200):
                 ctx.set_option("sparse_lds", mode)
                 bt = QpalmBatch(ctx, [q], ctx.default_settings(**dict(ST, enable_dual_termination=1)))
                 if iters:
@@ -561,7 +562,7 @@ def test_sparse_lds_forms_are_bit_identical_to_the_hbm_forms(ctx):
                     assert int(bt.info(0).status_val) == 1
                     res[mode] = (x[0].copy(), y[0].copy(), int(bt.info(0).iter))
                 bt.close()
-            for mode in (1, 6):
+            for mode in (1, 6, 200):
                 assert res[mode][2] == res[0][2] and np.array_equal(res[mode][0], res[0][0]) and np.array_equal(res[mode][1], res[0][1]), (ordering, mode)
     finally:
         ctx.set_option("sparse_factor", -1)
