@@ -76,8 +76,8 @@ QPD bool sp_level_needs_barrier(const SpArrays &S, int lev) {
 /* H = Q (+ A' Sigma_act A) (+ I / gamma) assembled column by column and factorised in the same pass (see the header).
  * with_AtSA = false, proximal = false: the second resident factor LD_Q of the dual objective (dev_solve, la == 7), into the value arrays the caller points S at. */
 QPNI void sp_factor(const qpg_view &V, int b, const int n, const SpArrays &S_, bool with_AtSA, bool proximal, double gamma) {
-  /* a column per GROUP of lanes: the columns of a sparse factor are short (a band: half a dozen entries), so a wavefront takes gpw = 1, 2
-   * or 4 columns of the level at a time (16 lanes each at 4) and a 512-thread workgroup up to 32 -- every step of a column is a chain of
+  /* a column per GROUP of lanes: the columns of a sparse factor are short (a band: half a dozen entries), so a wavefront takes gpw = 1, 2,
+   * 4 or 8 columns of the level at a time (8 lanes each at 8) and a 512-thread workgroup up to 64 -- every step of a column is a chain of
    * dependent HBM round trips, the groups' chains overlap.  Loops run to the wavefront's longest trip count with the other groups
    * masked off, so that the wavefront-level synchronisation points are met by every lane. */
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

@@ -140,7 +140,7 @@ typedef struct {
   int32_t seq_mode;         /* context option "sequential_rank_sums": -1 = where the factor can get near-singular (nonconvex QPs, QPs flagged by seq_hint), 1 = always, 0 = never */
   int32_t ls_hbm;           /* tests: >= 1 = the line search keeps its sort buffer in HBM (the LDS-tiled sort) whatever m; >= 2: tiles of at most that many entries */
   int32_t sp_lds;           /* context option "sparse_lds" (default 1): columns are accumulated, and right-hand sides solved, in LDS where they fit (0: the HBM forms) */
-  int32_t sp_gpw;           /* columns a wavefront factorises at a time (1, 2 or 4 groups of 64 / sp_gpw lanes): sp_wv holds wavefronts x sp_gpw work vectors per slot */
+  int32_t sp_gpw;           /* columns a wavefront factorises at a time (1, 2, 4 or 8 groups of 64 / sp_gpw lanes): sp_wv holds wavefronts x sp_gpw work vectors per slot */
   qpg_scalars *sc; /* [B] */
   qpg_settings *settings; /* [1] */
   int32_t *queue; /* [64 + QPG_CU_KEYS]: [0] work-queue head; [64 + key] workgroups that have arrived on compute unit `key` in this launch */
