@@ -76,14 +76,20 @@ def scan(path):
             block = None
             continue
         if _EXEC_RESTORE.match(s):
-            out.extend((fn, block, pl, ps, outside) for (pl, ps, outside) in pending)
+            out.extend((fn, block, pl, ps, outside) for (pl, ps, outside, _pd) in pending)
             block = None
             continue
         if op.startswith(("v_", "ds_", "flat_", "global_", "scratch_", "buffer_")):
             dst, src = _dst_src(s)
             # a pure save (copy / AGPR move / spill / writelane) of a register this block has not written = a value from before the region
             outside = bool(_SAVE.match(s)) and not (src & written) and bool(src)
-            pending.append((ln, s, outside))
+            # a copy that a later instruction of the SAME block reads before the restore is the region's own arithmetic (round 6: the body of
+            # a one-block region builds a 64-bit index from a loop-invariant zero, `v_mov v13, v7; v_lshl_add_u64 .., v[12:13], ..; flat_load`),
+            # not a value parked for the lanes that are off: the fault's copies sit in front of the restore for use behind it
+            for k, (pl, ps, po, pd) in enumerate(pending):
+                if po and (pd & src):
+                    pending[k] = (pl, ps, False, pd)
+            pending.append((ln, s, outside, dst))
             written |= dst
         elif op.startswith("s_") and op not in _PASS_THROUGH:
             block = None  # control flow or another exec write: no longer the block prologue

@@ -112,3 +112,28 @@ def test_gate_does_not_flag_the_entry_of_a_divergent_region(tmp_path):
     g = tmp_path / "restore.s"   # ... while the same copy ahead of a restore from a register the block did not derive from exec stays flagged
     g.write_text(REGION_ENTRY.replace("s_and_b64 s[2:3], s[0:1], s[2:3]", "s_nop 0"))
     assert [x[3] for x in mod.copies(mod.scan(str(g)))] == ["v_mov_b32_e32 v8, v124"]
+
+
+REGION_BODY = """
+_ZN5qp5128sp_solveEiRKNS_8SpArraysEPd:
+.LBB9_110:                              ;   in Loop: Header=BB9_87 Depth=1
+	v_mov_b32_e32 v13, v7
+	v_lshl_add_u64 v[20:21], v[12:13], 2, v[14:15]
+	flat_load_dword v68, v[20:21]
+	s_or_b64 exec, exec, s[16:17]
+	s_and_saveexec_b64 s[16:17], s[8:9]
+	s_cbranch_execz .LBB9_109
+"""
+
+
+def test_gate_does_not_flag_a_copy_the_region_itself_consumes(tmp_path):
+    """round 6 (pipelined sparse solves): the body of a one-block divergent region builds a 64-bit index from a loop-invariant zero and loads
+    through it -- the copy is read before the restore, it is not a value parked for the lanes that are off; the same copy NOT read before the
+    restore stays a finding"""
+    mod = _scan()
+    f = tmp_path / "body.s"
+    f.write_text(REGION_BODY)
+    assert mod.copies(mod.scan(str(f))) == []
+    g = tmp_path / "parked.s"
+    g.write_text(REGION_BODY.replace("v[12:13], 2", "v[30:31], 2"))
+    assert [x[3] for x in mod.copies(mod.scan(str(g)))] == ["v_mov_b32_e32 v13, v7"]
