@@ -154,6 +154,8 @@ void qpg_ctx_destroy(qpg_ctx *ctx);
  *   "queue_order"           1 (default) = a launch of more QPs than resident slots starts the members in descending order of the kernel time of
  *                           their previous solve (the launch's tail is then made of short solves); 0 = index order.  Never changes a result.
  *   "sparse_factor", "sparse_ordering"   the sparse L D L' and its ordering (qpg_batch_sparse_info / qpg_batch_sparse_perm below)
+ *   "sparse_gpw"            columns of a level a wavefront of the sparse factorisation takes at a time: 1, 2, 4 or 8 groups of 64 / gpw lanes (default 8,
+ *                           halved while the work vectors of all resident factors would exceed 4 GB).  Never changes a result.
  *   "sparse_lds"            1 (default) = the sparse factorisation accumulates a column, the sparse solves keep the right-hand side and the path
  *                           updates their work vector in LDS where they fit; 0 = the forms on vectors in HBM (same iterates bit for bit: A/B and
  *                           tests); >= 2 = LDS only for columns of at most that many entries (tests)

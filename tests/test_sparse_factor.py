@@ -568,3 +568,29 @@ def test_sparse_lds_forms_are_bit_identical_to_the_hbm_forms(ctx):
         ctx.set_option("sparse_factor", -1)
         ctx.set_option("sparse_ordering", -1)
         ctx.set_option("sparse_lds", 1)
+
+
+def test_sparse_columns_per_wavefront_do_not_change_the_iterates(ctx):
+    """Round 6: a wavefront factorises 1, 2, 4 or 8 columns of a level at a time (context option "sparse_gpw"; the default went from four groups of
+    16 lanes to eight groups of eight).  Which lanes own a column changes neither the operations of an entry nor their order: same iterates bit for
+    bit, same iteration count -- for a band under nested dissection, a forest of blocks and an arrow (columns longer than a group has lanes)."""
+    cases = [(sparse_qp(90, "banded", seed=11), 1), (sparse_qp(96, "blocks", seed=11), 0), (sparse_qp(60, "arrow", seed=11), 1)]
+    ctx.set_option("sparse_factor", 1)
+    try:
+        for q, ordering in cases:
+            ctx.set_option("sparse_ordering", ordering)
+            res = {}
+            for gpw in (8, 4, 2, 1):
+                ctx.set_option("sparse_gpw", gpw)
+                bt = QpalmBatch(ctx, [q], ctx.default_settings(**ST))
+                bt.solve()
+                x, y = bt.solution()
+                assert int(bt.info(0).status_val) == 1
+                res[gpw] = (x[0].copy(), y[0].copy(), int(bt.info(0).iter))
+                bt.close()
+            for gpw in (4, 2, 1):
+                assert res[gpw][2] == res[8][2] and np.array_equal(res[gpw][0], res[8][0]) and np.array_equal(res[gpw][1], res[8][1]), (ordering, gpw)
+    finally:
+        ctx.set_option("sparse_factor", -1)
+        ctx.set_option("sparse_ordering", -1)
+        ctx.set_option("sparse_gpw", 0)
